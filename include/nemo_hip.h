@@ -1,0 +1,150 @@
+/*
+ * nemo_hip.h -- C ABI of libnemo_hip.so, the MI355X (gfx950) render-and-compare
+ * pose solver that stands in for the PyTorch3D rasterizer + torch autograd +
+ * torch.optim.Adam inside the reference's MeshPoseSolveAll inference path.
+ *
+ * Conventions
+ *  - every pointer named d_* is a DEVICE pointer owned by the caller (for the
+ *    Python host: tensor.data_ptr() of a contiguous torch tensor), 16-byte aligned;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *  - every call returns 0 on success or a negative code (NEMO_ERR_*, or
+ *    -(1000 + hipError_t)); nemo_last_error() gives the text.  Nothing aborts;
+ *  - no entry point below the "setup" group allocates or synchronises;
+ *  - meshes hold PRE-PROCESSED vertices (x,y,z)->(x,z,-y) as the reference's
+ *    pre_process_mesh_pascal does (code/lib/MeshUtils.py:115-117);
+ *  - feature maps are PIXEL-MAJOR f32 [n_img][h][w][D] (the reference's
+ *    [D][h][w] maps, code/MeshPoseSolveAll.py:218, transposed once on upload);
+ *  - a "job" is one (image, mesh) pair; d_img_idx / d_mesh_idx (int32[N]) select
+ *    them, NULL meaning identity / mesh 0.
+ *
+ * file:line citations are into /root/reference (Angtian/NeMo).
+ */
+#ifndef NEMO_HIP_H
+#define NEMO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NEMO_OK 0
+#define NEMO_ERR_ARG (-1)         /* bad argument / shape */
+#define NEMO_ERR_UNSUPPORTED (-2) /* size outside what the kernels were built for */
+#define NEMO_ERR_STATE (-3)       /* call order (e.g. schedule not set) */
+#define NEMO_ERR_HIP_BASE (-1000) /* -(1000 + hipError_t) */
+
+typedef struct nemo_ctx nemo_ctx;
+
+/* Rasterizer / camera / loss configuration: RasterizationSettings(image_size=S,
+ * blur_radius=0, faces_per_pixel=1, bin_size=0) + OpenGLPerspectiveCameras(fov)
+ * + center_crop_fun(map_shape, (S,S)) (code/MeshPoseSolveAll.py:180-191,204). */
+typedef struct {
+  int32_t raster_size;         /* S = max(H,W)//8 (:171) */
+  int32_t win_h, win_w;        /* feature-map shape h, w (:191) */
+  int32_t win_r0, win_c0;      /* crop origin; <0 = centred as lib/MeshUtils.py:148-150 */
+  int32_t feat_dim;            /* D: 128 or 256 */
+  float ndc_scale;             /* 1/tan(fov/2) of OpenGLPerspectiveCameras (:180) */
+  int32_t perspective_correct; /* PyTorch3D 0.2.0: 0; FoV cameras in >=0.4: 1 */
+  int32_t clutter;             /* 1: loss_fun (:58-59); 0: loss_fun0 / turn_off_clutter (:50-56) */
+  double k_eps;                /* PyTorch3D kEpsilon (1e-8 current sources) */
+} nemo_config;
+
+/* ---- setup (may allocate / synchronise) ---------------------------------- */
+
+/* Replaces building cameras + RasterizationSettings + MeshRasterizer
+ * (code/MeshPoseSolveAll.py:180-190). */
+int nemo_ctx_create(const nemo_config *cfg, nemo_ctx **out);
+int nemo_ctx_destroy(nemo_ctx *ctx);
+const char *nemo_last_error(const nemo_ctx *ctx); /* ctx may be NULL (global slot) */
+
+/* Replaces MeshInterpolateModule.__init__ / update_memory (lib/MeshUtils.py:154-193):
+ * registers one mesh (device pointers stay owned by the caller and must outlive
+ * the context); the vertex bank f32[V][D] is indexed through faces instead of
+ * materialising face_memory.  Returns the mesh id (>= 0) or an error. */
+int nemo_mesh_register(nemo_ctx *ctx, const float *d_verts, int32_t V, const int32_t *d_faces,
+                       int32_t F, const float *d_bank);
+
+/* Adam / ExponentialLR schedule (code/MeshPoseSolveAll.py:230-231,249-250;
+ * torch.optim.Adam): host table f32[steps][2] = {lr_t/(1-b1^t), sqrt(1-b2^t)},
+ * prepared in double by the caller exactly like torch's Python side. */
+int nemo_set_schedule(nemo_ctx *ctx, const float *h_tab, int32_t steps, float beta1, float beta2,
+                      float eps);
+
+/* ---- hot path (asynchronous on `stream`, no allocation) ------------------- */
+
+/* campos_to_R_T (lib/MeshUtils.py:104-111): look_at_rotation(C, at=0, up=+y) @
+ * rotation_theta(theta), T = -R^T C (+ extra_trans, may be NULL).
+ * d_C f32[N][3], d_theta f32[N] -> d_R f32[N][9] (row-major), d_T f32[N][3]. */
+int nemo_campos_to_R_T(nemo_ctx *ctx, const float *d_C, const float *d_theta, const float *d_extra,
+                       int32_t N, float *d_R, float *d_T, void *stream);
+
+/* MeshRasterizer.forward -> rasterize_meshes naive, K=1 (lib/MeshUtils.py:83-85),
+ * already cropped to the window (:226).  d_pix_to_face i32[N][h][w] (-1 empty,
+ * face ids LOCAL to the job's mesh), d_bary f32[N][h][w][3] (-1 empty),
+ * d_zbuf f32[N][h][w] or NULL. */
+int nemo_rasterize(nemo_ctx *ctx, const int32_t *d_mesh_idx, const float *d_R, const float *d_T,
+                   int32_t N, int32_t *d_pix_to_face, float *d_bary, float *d_zbuf, void *stream);
+
+/* interpolate_face_attributes (lib/MeshUtils.py:129): d_out f32[N][h][w][D],
+ * zero where pix_to_face == -1. */
+int nemo_interpolate(nemo_ctx *ctx, const int32_t *d_mesh_idx, const int32_t *d_pix_to_face,
+                     const float *d_bary, int32_t N, float *d_out, void *stream);
+
+/* Backward of rasterize+interpolate for the autograd-compatible module path
+ * (loss.backward() at code/MeshPoseSolveAll.py:240 through lib/MeshUtils.py:122-133):
+ * d_grad_out f32[N][h][w][D] -> d_grad_R f32[N][9], d_grad_T f32[N][3].  Coverage is
+ * recomputed from (R, T): deterministic, hence identical to nemo_rasterize's. */
+int nemo_interpolate_backward(nemo_ctx *ctx, const int32_t *d_mesh_idx, const float *d_R,
+                              const float *d_T, const float *d_grad_out, int32_t N,
+                              float *d_grad_R, float *d_grad_T, void *stream);
+
+/* Clutter score (code/MeshPoseSolveAll.py:207,220; K-vector variant
+ * lib/MeshUtils.py:273-275): d_out[n][p] = max_k <d_cbank[k], feat[n][p]>,
+ * d_cbank f32[K][D]; the pixels x clutter-bank contraction runs on MFMA. */
+int nemo_clutter_score(nemo_ctx *ctx, const float *d_feat, int32_t n_img, const float *d_cbank,
+                       int32_t K, float *d_out, void *stream);
+
+/* One render-and-compare evaluation per job at given poses: object score
+ * (:237), loss (:238), and dL/dC, dL/dtheta as loss.backward() (:240) would
+ * leave them in C.grad / theta.grad.  d_loss f32[N], d_grad f32[N][4]
+ * (gCx,gCy,gCz,gtheta; may be NULL), d_ncov i32[N] (may be NULL). */
+int nemo_score_fwd_bwd(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx,
+                       const int32_t *d_mesh_idx, const float *d_feat, const float *d_clu,
+                       const float *d_C, const float *d_theta, float *d_loss, float *d_grad,
+                       int32_t *d_ncov, void *stream);
+
+/* get_pre_render_samples + get_init_pos_rendered (code/MeshPoseSolveAll.py:62-100):
+ * loss of every grid pose for every job, first minimum wins.
+ * d_grid_C f32[n_grids][G][3], d_grid_theta f32[n_grids][G]; d_grid_idx i32[N]
+ * picks the grid per job (NULL = grid 0; the reference uses one distance per
+ * category, :150-151,169).  Outputs: d_C0 f32[N][3], d_theta0 f32[N],
+ * d_best i32[N] (may be NULL), d_losses f32[N][G] scratch/output (required). */
+int nemo_grid_search(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t *d_mesh_idx,
+                     const int32_t *d_grid_idx, const float *d_feat, const float *d_clu,
+                     const float *d_grid_C, const float *d_grid_theta, int32_t G, float *d_losses,
+                     float *d_C0, float *d_theta0, int32_t *d_best, void *stream);
+
+/* The 300-step solve (code/MeshPoseSolveAll.py:227-250): render, score, loss,
+ * backward and Adam on (Cx,Cy,Cz,theta) fused in one persistent launch, one
+ * workgroup per job; schedule from nemo_set_schedule.  d_pose f32[N][4]
+ * = final (Cx,Cy,Cz,theta), d_loss f32[N] = loss at the last evaluated iterate,
+ * d_trace f32[N][steps][9] = (C, theta, loss, gC, gtheta) at the start of every
+ * step, or NULL. */
+int nemo_solve(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t *d_mesh_idx,
+               const float *d_feat, const float *d_clu, const float *d_C0, const float *d_theta0,
+               float *d_pose, float *d_loss, float *d_trace, void *stream);
+
+/* Bytes the fused kernels read per covered pixel and step: 4*D + 4. */
+int64_t nemo_bytes_per_covered_pixel(const nemo_ctx *ctx);
+
+/* Covered-pixel-steps accumulated by nemo_solve / nemo_grid_search / score calls
+ * since the counter was last reset (device counter, read back synchronously):
+ * the n_cov sum that prices the algorithmic HBM traffic. */
+int nemo_counter_reset(nemo_ctx *ctx, void *stream);
+int nemo_counter_read(nemo_ctx *ctx, uint64_t *out_covered_pixel_steps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEMO_HIP_H */

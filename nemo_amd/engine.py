@@ -1,0 +1,213 @@
+"""PoseEngine: torch-tensor front-end of libnemo_hip.so.
+
+PyTorch is plumbing here (device memory, streams); every computation on the pose
+path is a hand-written HIP kernel behind the C ABI of include/nemo_hip.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .synthetic import adam_table, ndc_scale
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(t, dtype, name, device):
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f'{name}: expected a torch tensor')
+    if t.device != device:
+        raise ValueError(f'{name}: tensor on {t.device}, engine on {device}')
+    if t.dtype != dtype:
+        raise TypeError(f'{name}: expected {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise ValueError(f'{name}: tensor must be contiguous')
+    return t
+
+
+class PoseEngine:
+    """One rasterizer/loss configuration + its registered meshes on one GPU.
+
+    Mirrors what the reference builds at code/MeshPoseSolveAll.py:180-191,204:
+    cameras(fov), RasterizationSettings(image_size=S, blur 0, K=1, naive) and the
+    centre-crop to the feature-map shape.
+    """
+
+    def __init__(self, raster_size: int, map_shape: Sequence[int], feat_dim: int = 128,
+                 fov: float = 12.0, perspective_correct: bool = False, clutter: bool = True,
+                 k_eps: float = 1e-8, device: str | torch.device = 'cuda:0', crop_origin=None):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise _lib.NemoHipError('PoseEngine needs a GPU device; there is no CPU fallback')
+        torch.cuda.set_device(self.device)
+        self.S = int(raster_size)
+        self.h, self.w = int(map_shape[0]), int(map_shape[1])
+        self.D = int(feat_dim)
+        self.ndc_scale = ndc_scale(fov)
+        r0, c0 = (-1, -1) if crop_origin is None else crop_origin
+        self.cfg = _lib.NemoConfig(self.S, self.h, self.w, r0, c0, self.D, self.ndc_scale,
+                                   int(perspective_correct), int(clutter), float(k_eps))
+        self.ctx = C.c_void_p()
+        _lib.check(None, self.lib.nemo_ctx_create(C.byref(self.cfg), C.byref(self.ctx)), 'nemo_ctx_create')
+        self._keep = []  # tensors registered with the library must outlive it
+        self.n_meshes = 0
+        self.steps = 0
+
+    def close(self):
+        if getattr(self, 'ctx', None) is not None and self.ctx:
+            self.lib.nemo_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ setup
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def register_mesh(self, verts, faces, bank) -> int:
+        """verts: PRE-PROCESSED [V,3] f32 (x,z,-y); faces [F,3] int; bank [V,D] f32."""
+        v = torch.as_tensor(np.asarray(verts) if not torch.is_tensor(verts) else verts,
+                            dtype=torch.float32).to(self.device).contiguous()
+        f = torch.as_tensor(np.asarray(faces) if not torch.is_tensor(faces) else faces).to(
+            device=self.device, dtype=torch.int32).contiguous()
+        b = torch.as_tensor(np.asarray(bank) if not torch.is_tensor(bank) else bank,
+                            dtype=torch.float32).to(self.device).contiguous()
+        if b.shape != (v.shape[0], self.D):
+            raise ValueError(f'bank shape {tuple(b.shape)} != ({v.shape[0]}, {self.D})')
+        if int(f.min()) < 0 or int(f.max()) >= v.shape[0]:
+            raise ValueError('face index outside the vertex array')
+        mid = _lib.check(self.ctx, self.lib.nemo_mesh_register(self.ctx, _ptr(v), v.shape[0], _ptr(f),
+                                                               f.shape[0], _ptr(b)), 'nemo_mesh_register')
+        self._keep.append((v, f, b))
+        self.n_meshes = mid + 1
+        return mid
+
+    def set_schedule(self, steps=300, lr=0.05, betas=(0.4, 0.6), eps=1e-8, decay_every=100, gamma=0.2):
+        tab = np.ascontiguousarray(adam_table(steps, lr, betas[0], betas[1], decay_every, gamma))
+        _lib.check(self.ctx, self.lib.nemo_set_schedule(self.ctx, tab.ctypes.data_as(C.c_void_p), steps,
+                                                        betas[0], betas[1], eps), 'nemo_set_schedule')
+        self.steps = steps
+        return tab
+
+    # ------------------------------------------------------------------ helpers
+    def _f32(self, t, name):
+        return _chk(t, torch.float32, name, self.device)
+
+    def _i32(self, t, name):
+        return _chk(t, torch.int32, name, self.device)
+
+    def _empty(self, shape, dtype=torch.float32):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    # ------------------------------------------------------------------ hot path
+    def campos_to_R_T(self, C_, theta, extra=None):
+        C_, theta = self._f32(C_, 'C'), self._f32(theta, 'theta')
+        N = C_.shape[0]
+        R, T = self._empty((N, 3, 3)), self._empty((N, 3))
+        _lib.check(self.ctx, self.lib.nemo_campos_to_R_T(self.ctx, _ptr(C_), _ptr(theta),
+                                                         _ptr(self._f32(extra, 'extra')), N, _ptr(R),
+                                                         _ptr(T), self._stream()), 'nemo_campos_to_R_T')
+        return R, T
+
+    def rasterize(self, R, T, mesh_idx=None, want_zbuf=False):
+        R, T = self._f32(R, 'R'), self._f32(T, 'T')
+        N = R.shape[0]
+        p2f = self._empty((N, self.h, self.w), torch.int32)
+        bary = self._empty((N, self.h, self.w, 3))
+        zb = self._empty((N, self.h, self.w)) if want_zbuf else None
+        _lib.check(self.ctx, self.lib.nemo_rasterize(self.ctx, _ptr(self._i32(mesh_idx, 'mesh_idx')), _ptr(R),
+                                                     _ptr(T), N, _ptr(p2f), _ptr(bary), _ptr(zb),
+                                                     self._stream()), 'nemo_rasterize')
+        return (p2f, bary, zb) if want_zbuf else (p2f, bary)
+
+    def interpolate(self, p2f, bary, mesh_idx=None):
+        p2f, bary = self._i32(p2f, 'pix_to_face'), self._f32(bary, 'bary')
+        N = p2f.shape[0]
+        out = self._empty((N, self.h, self.w, self.D))
+        _lib.check(self.ctx, self.lib.nemo_interpolate(self.ctx, _ptr(self._i32(mesh_idx, 'mesh_idx')), _ptr(p2f),
+                                                       _ptr(bary), N, _ptr(out), self._stream()),
+                   'nemo_interpolate')
+        return out
+
+    def interpolate_backward(self, R, T, grad_out, mesh_idx=None):
+        R, T, grad_out = self._f32(R, 'R'), self._f32(T, 'T'), self._f32(grad_out, 'grad_out')
+        N = R.shape[0]
+        gR, gT = self._empty((N, 3, 3)), self._empty((N, 3))
+        _lib.check(self.ctx, self.lib.nemo_interpolate_backward(
+            self.ctx, _ptr(self._i32(mesh_idx, 'mesh_idx')), _ptr(R), _ptr(T), _ptr(grad_out), N, _ptr(gR),
+            _ptr(gT), self._stream()), 'nemo_interpolate_backward')
+        return gR, gT
+
+    def clutter_score(self, feat, cbank):
+        feat, cbank = self._f32(feat, 'feat'), self._f32(cbank, 'cbank')
+        if cbank.dim() == 1:
+            cbank = cbank[None]
+        n_img = feat.shape[0]
+        out = self._empty((n_img, self.h, self.w))
+        _lib.check(self.ctx, self.lib.nemo_clutter_score(self.ctx, _ptr(feat), n_img, _ptr(cbank), cbank.shape[0],
+                                                         _ptr(out), self._stream()), 'nemo_clutter_score')
+        return out
+
+    def score_fwd_bwd(self, feat, clu, C_, theta, img_idx=None, mesh_idx=None, want_grad=True):
+        C_, theta = self._f32(C_, 'C'), self._f32(theta, 'theta')
+        N = C_.shape[0]
+        loss = self._empty((N,))
+        grad = self._empty((N, 4)) if want_grad else None
+        ncov = self._empty((N,), torch.int32)
+        _lib.check(self.ctx, self.lib.nemo_score_fwd_bwd(
+            self.ctx, N, _ptr(self._i32(img_idx, 'img_idx')), _ptr(self._i32(mesh_idx, 'mesh_idx')),
+            _ptr(self._f32(feat, 'feat')), _ptr(self._f32(clu, 'clu')), _ptr(C_), _ptr(theta), _ptr(loss),
+            _ptr(grad), _ptr(ncov), self._stream()), 'nemo_score_fwd_bwd')
+        return loss, grad, ncov
+
+    def grid_search(self, feat, clu, grid_C, grid_theta, n_jobs=None, img_idx=None, mesh_idx=None,
+                    grid_idx=None, losses=None):
+        grid_C, grid_theta = self._f32(grid_C, 'grid_C'), self._f32(grid_theta, 'grid_theta')
+        G = grid_theta.shape[-1]
+        N = n_jobs if n_jobs is not None else (img_idx.shape[0] if img_idx is not None else feat.shape[0])
+        if losses is None:
+            losses = self._empty((N, G))
+        C0, th0 = self._empty((N, 3)), self._empty((N,))
+        best = self._empty((N,), torch.int32)
+        _lib.check(self.ctx, self.lib.nemo_grid_search(
+            self.ctx, N, _ptr(self._i32(img_idx, 'img_idx')), _ptr(self._i32(mesh_idx, 'mesh_idx')),
+            _ptr(self._i32(grid_idx, 'grid_idx')), _ptr(self._f32(feat, 'feat')), _ptr(self._f32(clu, 'clu')),
+            _ptr(grid_C), _ptr(grid_theta), G, _ptr(self._f32(losses, 'losses')), _ptr(C0), _ptr(th0),
+            _ptr(best), self._stream()), 'nemo_grid_search')
+        return C0, th0, best, losses
+
+    def solve(self, feat, clu, C0, theta0, img_idx=None, mesh_idx=None, want_trace=False):
+        C0, theta0 = self._f32(C0, 'C0'), self._f32(theta0, 'theta0')
+        N = C0.shape[0]
+        pose, loss = self._empty((N, 4)), self._empty((N,))
+        trace = self._empty((N, self.steps, 9)) if want_trace else None
+        _lib.check(self.ctx, self.lib.nemo_solve(
+            self.ctx, N, _ptr(self._i32(img_idx, 'img_idx')), _ptr(self._i32(mesh_idx, 'mesh_idx')),
+            _ptr(self._f32(feat, 'feat')), _ptr(self._f32(clu, 'clu')), _ptr(C0), _ptr(theta0), _ptr(pose),
+            _ptr(loss), _ptr(trace), self._stream()), 'nemo_solve')
+        return (pose, loss, trace) if want_trace else (pose, loss)
+
+    # ------------------------------------------------------------------ accounting
+    def bytes_per_covered_pixel(self) -> int:
+        return int(self.lib.nemo_bytes_per_covered_pixel(self.ctx))
+
+    def counter_reset(self):
+        _lib.check(self.ctx, self.lib.nemo_counter_reset(self.ctx, self._stream()), 'nemo_counter_reset')
+
+    def counter_read(self) -> int:
+        v = C.c_uint64()
+        _lib.check(self.ctx, self.lib.nemo_counter_read(self.ctx, C.byref(v)), 'nemo_counter_read')
+        return int(v.value)
