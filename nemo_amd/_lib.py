@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libnemo_hip.so')
+# NEMO_HIP_LIB selects a diagnostic build of the same library (e.g. the phase-stamp build).
+LIB_PATH = os.environ.get('NEMO_HIP_LIB') or os.path.join(_HERE, 'lib', 'libnemo_hip.so')
 
 EXPORTS = ['nemo_ctx_create', 'nemo_ctx_destroy', 'nemo_last_error', 'nemo_mesh_register',
            'nemo_set_schedule', 'nemo_campos_to_R_T', 'nemo_rasterize', 'nemo_interpolate',

@@ -23,6 +23,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "nemo_hip.h"
@@ -40,6 +41,7 @@ constexpr int LDS_BUDGET = 80 * 1024;  // two workgroups per CU (160 KiB LDS)
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
+typedef unsigned short us4 __attribute__((ext_vector_type(4)));
 // Pointers that come out of the mesh table are global memory; saying so lets the
 // compiler emit global_load (vmcnt only) instead of flat_load.
 #define GAS __attribute__((address_space(1)))
@@ -64,6 +66,7 @@ struct KParams {
   float inv_hw;
   int cap;   // z-buffer capacity in pixels
   int vmax;  // vertex capacity of the LDS arrays
+  int fmax;  // face capacity of the LDS arrays
 };
 
 // ---------------------------------------------------------------- small math
@@ -255,7 +258,8 @@ __device__ __forceinline__ float sum8(float v) {
 template <int LPP>
 __device__ __forceinline__ float sum_group(float v) {
   v = sum8(v);
-  if (LPP == 16) v += dpp_mov<0x140>(v);  // row_mirror: lanes 0-7 <-> 15-8 of each row of 16
+  if (LPP >= 16) v += dpp_mov<0x140>(v);  // row_mirror: lanes 0-7 <-> 15-8 of each row of 16
+  if (LPP >= 32) v += __shfl_xor(v, 16);
   return v;
 }
 __device__ __forceinline__ float wave_sum(float v) {
@@ -274,34 +278,61 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---------------------------------------------------------------- phase stamps
+// Diagnostic build only (-DNEMO_STAMPS): wave 0 / lane 0 of every workgroup adds the
+// cycles it spent per phase (barrier waits included) into g_stamps; the shipped
+// library contains none of this.
+#ifndef NEMO_ABL
+#define NEMO_ABL 0  // diagnostic builds: 1 = no feature-row loads, 2 = no bank-row loads, 3 = neither, 4 = no phase A
+#endif
+#ifdef NEMO_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP_DECL unsigned long long st_prev = (threadIdx.x == 0) ? __builtin_readcyclecounter() : 0ull
+#define STAMP(i)                                                         \
+  do {                                                                   \
+    if (threadIdx.x == 0) {                                              \
+      const unsigned long long now_ = __builtin_readcyclecounter();      \
+      atomicAdd(&g_stamps[i], now_ - st_prev);                           \
+      st_prev = now_;                                                    \
+    }                                                                    \
+  } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#endif
+
 // ---------------------------------------------------------------- LDS layout
 struct Lds {
   u64 *zb;               // [cap] packed z-buffer
-  float *sv;             // [3*vmax] screen verts (u, t, z_view)
-  float *xw;             // [3*vmax] world verts
+  f4 *sv;                // [vmax] screen verts (u, t, z_view, -)
+  us4 *fc;               // [fmax] face vertex ids (i0, i1, i2, -) as 16-bit
+  float *ndc;            // [S] pixel-centre NDC coordinate of flipped index a: PixToNdc(a, S)
   unsigned short *list;  // [NW][list_stride] covered-pixel lists
   float *red;            // [NW][RED_N]
   float *ust;            // [UST_N] workgroup-uniform state (camera, Adam)
+  float *gbuf;           // [NW][64*3] dot products handed from phase A to phase B
   int list_stride;
 };
 
-__host__ __device__ inline size_t lds_bytes(int cap, int vmax, int wmax) {
-  size_t b = (size_t)cap * 8 + (size_t)vmax * 24;
+__host__ __device__ inline size_t lds_bytes(int cap, int vmax, int fmax, int wmax, int S) {
+  size_t b = (size_t)cap * 8 + (size_t)vmax * 16 + (size_t)fmax * 8;
   size_t ls = ((size_t)cap / NW + wmax + 63) & ~(size_t)63;
   b += ls * NW * 2;
-  b += (NW * RED_N + UST_N) * 4 + 64;
+  b += (NW * RED_N + UST_N + NW * 64 * 3 + ((S + 3) & ~3)) * 4 + 64;
   return (b + 15) & ~(size_t)15;
 }
 
 __device__ __forceinline__ Lds lds_carve(unsigned char *base, const KParams &P) {
   Lds L;
   L.zb = (u64 *)base;
-  L.sv = (float *)(base + (size_t)P.cap * 8);
-  L.xw = L.sv + 3 * P.vmax;
+  L.sv = (f4 *)(base + (size_t)P.cap * 8);
+  L.fc = (us4 *)(L.sv + P.vmax);
   L.list_stride = (P.cap / NW + P.w + 63) & ~63;
-  L.list = (unsigned short *)(L.xw + 3 * P.vmax);
+  L.list = (unsigned short *)(L.fc + P.fmax);
   L.red = (float *)(L.list + (size_t)L.list_stride * NW);
   L.ust = L.red + NW * RED_N;
+  L.gbuf = L.ust + UST_N;
+  L.ndc = L.gbuf + NW * 64 * 3;
   return L;
 }
 
@@ -310,6 +341,13 @@ struct EmitOut {  // standalone rasterizer outputs (window), may be null
   float *bary;
   float *zbuf;
 };
+
+__device__ __forceinline__ void load_face_verts(const Lds &L, int i0, int i1, int i2, float *v) {
+  const f4 s0 = L.sv[i0], s1 = L.sv[i1], s2 = L.sv[i2];
+  v[0] = s0.x; v[1] = s0.y; v[2] = s0.z;
+  v[3] = s1.x; v[4] = s1.y; v[5] = s1.z;
+  v[6] = s2.x; v[7] = s2.y; v[8] = s2.z;
+}
 
 // Block totals left in LDS by eval_pose: red[wave][i], i = 0 loss_sum, 1 ncov,
 // 2..10 dL/dR, 11..13 dL/dT.  Summed over waves in a fixed order.
@@ -329,19 +367,19 @@ __device__ __forceinline__ float block_total(const Lds &L, int i) {
 template <int D, bool PERSP, bool GRAD, bool SCORE, bool RAW = false>
 __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, const float *__restrict__ feat,
                           const float *__restrict__ clu, EmitOut emit) {
-  constexpr int LPP = (D == 256) ? 16 : 8;  // lanes per pixel: 16 floats per lane per row
-  constexpr int GPW = 64 / LPP;             // pixels per wave iteration
-  constexpr int KIT = D / (4 * LPP);        // 16-byte loads per row per lane
+  constexpr int KIT = 4;                    // 16-byte loads per row per lane
+  constexpr int LPP = D / (4 * KIT);        // lanes per pixel: 8 (D=128) or 16 (D=256)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int S = P.S;
   const float Sf = (float)S;
   const int V = M.V, F = M.F;
   const float s = P.s;
-  const gi32p faces = as_global(M.faces);
+  const gf32p gverts = as_global(M.verts);
   const gf32p bank = as_global(M.bank);
   const gf32p gfeat = as_global(feat);
   const gf32p gclu = as_global(clu);
 
+  STAMP_DECL;
   // ---- 1. project vertices (MeshRasterizer.transform; order fixed in DESIGN.md)
   float umin = 3.0e38f, umax = -3.0e38f, tmin = 3.0e38f, tmax = -3.0e38f;
   {
@@ -350,12 +388,12 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
     const float m01 = R[1] * s, m11 = R[4] * s, m21 = R[7] * s, m31 = T[1] * s;
     const float r02 = R[2], r12 = R[5], r22 = R[8], t2 = T[2];
     for (int v = tid; v < V; v += NT) {
-      const float x = L.xw[3 * v], y = L.xw[3 * v + 1], z = L.xw[3 * v + 2];
+      const float x = gverts[3 * v], y = gverts[3 * v + 1], z = gverts[3 * v + 2];
       const float xc = ((x * m00 + y * m10) + z * m20) + m30;
       const float yc = ((x * m01 + y * m11) + z * m21) + m31;
       const float zv = ((x * r02 + y * r12) + z * r22) + t2;
       const float u = xc / zv, t = yc / zv;
-      L.sv[3 * v] = u; L.sv[3 * v + 1] = t; L.sv[3 * v + 2] = zv;
+      L.sv[v] = f4{u, t, zv, 0.0f};
       umin = fminf(umin, u); umax = fmaxf(umax, u);
       tmin = fminf(tmin, t); tmax = fmaxf(tmax, t);
     }
@@ -383,10 +421,24 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
     float f = ((fmaxf(fminf(vmax_, 4.0f), -4.0f) + 1.0f) * Sf - 1.0f) * 0.5f;
     return (int)ceilf(f) + 1;
   };
-  const int a_lo = max(lo_idx(umin), a_w0), a_hi = min(hi_idx(umax), a_w1);
-  const int b_lo = max(lo_idx(tmin), b_w0), b_hi = min(hi_idx(tmax), b_w1);
+  // [lo, hi] = indices i in [clip_lo, clip_hi] with vmin <= ndc[i] <= vmax, exactly
+  // (ndc[] is monotone; the estimate is off by at most one, the loops fix it up)
+  auto exact_range = [&](float vmin, float vmax_, int clip_lo, int clip_hi, int &lo, int &hi) {
+    lo = min(max(lo_idx(vmin) + 1, clip_lo), clip_hi + 1);
+    hi = max(min(hi_idx(vmax_) - 1, clip_hi), clip_lo - 1);
+    while (lo > clip_lo && L.ndc[lo - 1] >= vmin) --lo;
+    while (lo <= hi && L.ndc[lo] < vmin) ++lo;
+    while (hi < clip_hi && L.ndc[hi + 1] <= vmax_) ++hi;
+    while (hi >= lo && L.ndc[hi] > vmax_) --hi;
+  };
+  // workgroup-uniform values read back from LDS live in VGPRs unless told otherwise
+  const int a_lo = __builtin_amdgcn_readfirstlane(max(lo_idx(umin), a_w0));
+  const int a_hi = __builtin_amdgcn_readfirstlane(min(hi_idx(umax), a_w1));
+  const int b_lo = __builtin_amdgcn_readfirstlane(max(lo_idx(tmin), b_w0));
+  const int b_hi = __builtin_amdgcn_readfirstlane(min(hi_idx(tmax), b_w1));
   const int bw = a_hi - a_lo + 1;
   const bool empty_box = (bw <= 0) || (b_hi < b_lo);
+  STAMP(0);
 
   float loss_sum = 0.f;
   float GR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -401,169 +453,279 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       // ---- 2a. clear the band's z-buffer
       for (int i = tid; i < npx; i += NT) L.zb[i] = ~0ull;
       __syncthreads();
+      STAMP(1);
       // ---- 2b. face-parallel rasterisation (one thread per face)
       for (int f = tid; f < F; f += NT) {
-        const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+        const us4 fv_ = L.fc[f];
+          const int i0 = fv_.x, i1 = fv_.y, i2 = fv_.z;
         float v[9];
-        v[0] = L.sv[3 * i0]; v[1] = L.sv[3 * i0 + 1]; v[2] = L.sv[3 * i0 + 2];
-        v[3] = L.sv[3 * i1]; v[4] = L.sv[3 * i1 + 1]; v[5] = L.sv[3 * i1 + 2];
-        v[6] = L.sv[3 * i2]; v[7] = L.sv[3 * i2 + 1]; v[8] = L.sv[3 * i2 + 2];
+        load_face_verts(L, i0, i1, i2, v);
         if (face_degenerate(v, P.keps)) continue;
         const float xmin = fminf(fminf(v[0], v[3]), v[6]), xmax = fmaxf(fmaxf(v[0], v[3]), v[6]);
         const float ymin = fminf(fminf(v[1], v[4]), v[7]), ymax = fmaxf(fmaxf(v[1], v[4]), v[7]);
-        const int fa_lo = max(lo_idx(xmin), a_lo), fa_hi = min(hi_idx(xmax), a_hi);
-        const int fb_lo = max(lo_idx(ymin), bb), fb_hi = min(hi_idx(ymax), bb + nr - 1);
+        // exact index ranges of the pixel centres inside the face's bounding box (the test
+        // PyTorch3D applies per pixel), clipped to the object box / band
+        int fa_lo, fa_hi, fb_lo, fb_hi;
+        exact_range(xmin, xmax, a_lo, a_hi, fa_lo, fa_hi);
+        exact_range(ymin, ymax, bb, bb + nr - 1, fb_lo, fb_hi);
         if (fa_lo > fa_hi || fb_lo > fb_hi) continue;
         const float area = face_area_eps(v, P.keps);
         for (int b = fb_lo; b <= fb_hi; ++b) {
-          const float py = ndc_of(b, Sf);
-          if (py > ymax || py < ymin) continue;
+          const float py = L.ndc[b];
           for (int a = fa_lo; a <= fa_hi; ++a) {
-            const float px = ndc_of(a, Sf);
-            if (px > xmax || px < xmin) continue;
             Frag fr;
-            if (!frag_eval<PERSP>(px, py, v, area, fr)) continue;
+            if (!frag_eval<PERSP>(L.ndc[a], py, v, area, fr)) continue;
             const u64 key = ((u64)__float_as_uint(fr.pz) << 32) | (u64)(uint32_t)f;
             atomicMin(&L.zb[(b - bb) * bw + (a - a_lo)], key);
           }
         }
       }
       __syncthreads();
-      // ---- 2c. per-wave compaction of covered pixels (rows interleaved over waves)
-      unsigned short *mylist = L.list + (size_t)wave * L.list_stride;
-      int nmine = 0;
-      for (int r = wave; r < nr; r += NW) {
-        for (int c = lane; c < ((bw + 63) & ~63); c += 64) {
-          const int q = r * bw + c;
-          const bool cov = (c < bw) && (L.zb[q] != ~0ull);
-          const u64 mask = __ballot(cov);
-          if (cov) {
-            const int pos = nmine + __popcll(mask & ((1ull << lane) - 1ull));
-            mylist[pos] = (unsigned short)q;
-          }
-          nmine += __popcll(mask);
+      STAMP(2);
+      // ---- 2c. face-major list of the covered pixels: ordered by winning face, then
+      // row-major.  Thread t owns the contiguous face run [t*fpl, (t+1)*fpl), so a
+      // block-wide exclusive scan of the per-thread counts gives every thread its slot
+      // range; the order (hence every later float sum) is deterministic.
+      const uint32_t *zlo = (const uint32_t *)L.zb;  // low dword of a key = face id
+      const int fpl = (F + NT - 1) / NT;
+      const int fbeg = min(F, tid * fpl), fend = min(F, fbeg + fpl);
+      auto walk = [&](auto &&visit) {
+        for (int f = fbeg; f < fend; ++f) {
+          const us4 fv_ = L.fc[f];
+          const int i0 = fv_.x, i1 = fv_.y, i2 = fv_.z;
+          const f4 s0 = L.sv[i0], s1 = L.sv[i1], s2 = L.sv[i2];
+          int fa_lo, fa_hi, fb_lo, fb_hi;
+          exact_range(fminf(fminf(s0.x, s1.x), s2.x), fmaxf(fmaxf(s0.x, s1.x), s2.x), a_lo, a_hi, fa_lo, fa_hi);
+          exact_range(fminf(fminf(s0.y, s1.y), s2.y), fmaxf(fmaxf(s0.y, s1.y), s2.y), bb, bb + nr - 1, fb_lo, fb_hi);
+          for (int b = fb_lo; b <= fb_hi; ++b)
+            for (int a = fa_lo; a <= fa_hi; ++a) {
+              const int q = (b - bb) * bw + (a - a_lo);
+              if (zlo[2 * q] == (uint32_t)f) visit(q);
+            }
         }
+      };
+      int cnt = 0;
+      walk([&](int) { ++cnt; });
+      int incl = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
       }
-      ncov += (lane == 0) ? nmine : 0;
-      // (list entries are written and read by the same wave: LDS operations of
-      //  one wave complete in order, so no barrier is needed)
+      int *ired = (int *)L.red;
+      if (lane == 63) ired[wave * RED_N + 8] = incl;
+      __syncthreads();
+      int slot = incl - cnt, ntot = 0;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        const int t = ired[k * RED_N + 8];
+        slot += (k < wave) ? t : 0;
+        ntot += t;
+      }
+      ntot = __builtin_amdgcn_readfirstlane(ntot);
+      walk([&](int q) { L.list[slot++] = (unsigned short)q; });
+      ncov += (tid == 0) ? ntot : 0;
+      __syncthreads();
+      STAMP(3);
       if (!SCORE) {
         // standalone rasterizer: emit pix_to_face / bary / zbuf for covered pixels
-        for (int e = lane; e < nmine; e += 64) {
-          const int q = mylist[e];
+        for (int e = tid; e < ntot; e += NT) {
+          const int q = L.list[e];
           const int bl = q / bw, al = q - bl * bw;
           const int a = a_lo + al, b = bb + bl;
-          const int f = (int)(uint32_t)(L.zb[q] & 0xffffffffull);
-          const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+          const int f = (int)zlo[2 * q];
+          const us4 fv_ = L.fc[f];
+          const int i0 = fv_.x, i1 = fv_.y, i2 = fv_.z;
           float v[9];
-          v[0] = L.sv[3 * i0]; v[1] = L.sv[3 * i0 + 1]; v[2] = L.sv[3 * i0 + 2];
-          v[3] = L.sv[3 * i1]; v[4] = L.sv[3 * i1 + 1]; v[5] = L.sv[3 * i1 + 2];
-          v[6] = L.sv[3 * i2]; v[7] = L.sv[3 * i2 + 1]; v[8] = L.sv[3 * i2 + 2];
+          load_face_verts(L, i0, i1, i2, v);
           Frag fr;
           fr.b0 = fr.b1 = fr.b2 = fr.pz = -1.0f;
-          frag_eval<PERSP>(ndc_of(a, Sf), ndc_of(b, Sf), v, face_area_eps(v, P.keps), fr);
+          frag_eval<PERSP>(L.ndc[a], L.ndc[b], v, face_area_eps(v, P.keps), fr);
           const int p = (S - 1 - b - P.r0) * P.w + (S - 1 - a - P.c0);
           emit.p2f[p] = f;
           emit.bary[3 * p] = fr.b0; emit.bary[3 * p + 1] = fr.b1; emit.bary[3 * p + 2] = fr.b2;
           if (emit.zbuf) emit.zbuf[p] = fr.pz;
         }
-      } else {
-        // ---- 3. fused interpolate + score (+ backward): LPP lanes per pixel
+      } else if (ntot > 0) {
+        // ---- 3. fused interpolate + score (+ backward).  Each wave owns a contiguous
+        // segment of the face-major list and works through it in chunks of 64 pixels:
+        //  phase A (LPP lanes per pixel): 16-byte loads of the pixel's feature row and of
+        //    the face's three vertex-bank rows, three D-long dot products reduced with
+        //    DPP, results parked in a wave-private LDS buffer.  A lane group walks
+        //    consecutive list entries and re-reads a bank row only when that vertex slot
+        //    changes (the two triangles of a cuboid cell share two of their three slots).
+        //  phase B (one lane per pixel): barycentrics, object score, loss term and the
+        //    hand-derived backward to dL/dR, dL/dT accumulators.
+        // Both phases are wave-local (LDS operations of one wave complete in order), so
+        // there is no workgroup barrier inside this loop.
+        constexpr int GPW = 64 / LPP;
         const int gl = lane & (LPP - 1), grp = lane / LPP;
-        for (int base = 0; base < nmine; base += GPW) {
-          const int e = base + grp;
-          const bool act = e < nmine;
-          const int q = mylist[act ? e : nmine - 1];
+        float *gbuf = L.gbuf + wave * (64 * 3);
+        const int ws_b = (int)(((long long)ntot * wave) / NW), ws_e = (int)(((long long)ntot * (wave + 1)) / NW);
+        auto entry_p = [&](int e) {  // list entry -> window pixel index (row-major in the crop)
+          const int q = L.list[e];
           const int bl = q / bw, al = q - bl * bw;
-          const int a = a_lo + al, b = bb + bl;
-          const int f = (int)(uint32_t)(L.zb[q] & 0xffffffffull);
-          const int p = (S - 1 - b - P.r0) * P.w + (S - 1 - a - P.c0);
-          const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
-          const gf4p Fp = (gf4p)(gfeat + (size_t)p * D) + gl;
-          const gf4p B0 = (gf4p)(bank + (size_t)i0 * D) + gl;
-          const gf4p B1 = (gf4p)(bank + (size_t)i1 * D) + gl;
-          const gf4p B2 = (gf4p)(bank + (size_t)i2 * D) + gl;
-          float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+          return (S - 1 - (bb + bl) - P.r0) * P.w + (S - 1 - (a_lo + al) - P.c0);
+        };
+        f4 xn[KIT];  // feature row of this lane group's NEXT entry, always one load ahead
+        {
+          const int cn0 = min(64, ws_e - ws_b), per0 = (cn0 + GPW - 1) / GPW;
+          const gf4p Fp = (gf4p)(gfeat + (size_t)entry_p(ws_b + min(grp * per0, cn0 - 1)) * D) + gl;
 #pragma unroll
-          for (int k = 0; k < KIT; ++k) {
-            const f4 x = __builtin_nontemporal_load(Fp + LPP * k);
-            const f4 y0 = B0[LPP * k], y1 = B1[LPP * k], y2 = B2[LPP * k];
-            a0 = fmaf(x.x, y0.x, a0); a0 = fmaf(x.y, y0.y, a0); a0 = fmaf(x.z, y0.z, a0); a0 = fmaf(x.w, y0.w, a0);
-            a1 = fmaf(x.x, y1.x, a1); a1 = fmaf(x.y, y1.y, a1); a1 = fmaf(x.z, y1.z, a1); a1 = fmaf(x.w, y1.w, a1);
-            a2 = fmaf(x.x, y2.x, a2); a2 = fmaf(x.y, y2.y, a2); a2 = fmaf(x.z, y2.z, a2); a2 = fmaf(x.w, y2.w, a2);
+          for (int k = 0; k < KIT; ++k) xn[k] = __builtin_nontemporal_load(Fp + LPP * k);
+        }
+        for (int cb = ws_b; cb < ws_e; cb += 64) {
+          const int cn = min(64, ws_e - cb);
+          const int per = (cn + GPW - 1) / GPW;  // entries per lane group in this chunk
+          // first entry of this group in the next chunk (or a harmless reload at the very end)
+          const int cb2 = cb + 64;
+          const int cn2 = min(64, ws_e - cb2), per2 = (cn2 + GPW - 1) / GPW;
+          const int e_next_chunk = cb2 < ws_e ? cb2 + min(grp * per2, cn2 - 1) : cb + cn - 1;
+          // ---------------- phase A
+          {
+            int pf = -1, i0 = -1, i1 = -1, i2 = -1;
+            f4 y0[KIT], y1[KIT], y2[KIT];
+#pragma unroll
+            for (int k = 0; k < KIT; ++k) y0[k] = y1[k] = y2[k] = f4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < ((NEMO_ABL & 4) ? 0 : per); ++j) {
+              const int el = grp * per + j;
+              const int e = cb + min(el, cn - 1);
+              const int f = (int)zlo[2 * (int)L.list[e]];
+              // 1st: the loads this iteration depends on (bank rows of a changed vertex slot) ...
+              if (f != pf) {
+                pf = f;
+                const us4 fv_ = L.fc[f];
+                const int n0 = fv_.x, n1 = fv_.y, n2 = fv_.z;
+                if (n0 != i0) {
+                  i0 = n0;
+                  const gf4p B = (gf4p)(bank + (size_t)i0 * D) + gl;
+#pragma unroll
+                  for (int k = 0; k < KIT; ++k) y0[k] = (NEMO_ABL & 2) ? f4{(float)i0, 1.f, 2.f, 3.f} : B[LPP * k];
+                }
+                if (n1 != i1) {
+                  i1 = n1;
+                  const gf4p B = (gf4p)(bank + (size_t)i1 * D) + gl;
+#pragma unroll
+                  for (int k = 0; k < KIT; ++k) y1[k] = (NEMO_ABL & 2) ? f4{(float)i1, 1.f, 2.f, 3.f} : B[LPP * k];
+                }
+                if (n2 != i2) {
+                  i2 = n2;
+                  const gf4p B = (gf4p)(bank + (size_t)i2 * D) + gl;
+#pragma unroll
+                  for (int k = 0; k < KIT; ++k) y2[k] = (NEMO_ABL & 2) ? f4{(float)i2, 1.f, 2.f, 3.f} : B[LPP * k];
+                }
+              }
+              // ... 2nd: the next entry's feature row, which stays in flight (vmcnt is in
+              // order) while this entry's dot products wait only for the rows above
+              f4 x[KIT];
+#pragma unroll
+              for (int k = 0; k < KIT; ++k) x[k] = xn[k];
+              {  // unconditional: a conditional load would force a full vmcnt drain every iteration
+                const int en = (j + 1 < per) ? cb + min(el + 1, cn - 1) : e_next_chunk;
+                const gf4p Fp = (gf4p)(gfeat + (size_t)entry_p(en) * D) + gl;
+#pragma unroll
+                for (int k = 0; k < KIT; ++k)
+                  xn[k] = (NEMO_ABL & 1) ? f4{(float)en, 1.f, 2.f, 3.f} : __builtin_nontemporal_load(Fp + LPP * k);
+              }
+              f4 A0 = x[0] * 0.0f, A1 = A0, A2 = A0;
+#pragma unroll
+              for (int k = 0; k < KIT; ++k) {
+                A0 = __builtin_elementwise_fma(x[k], y0[k], A0);
+                A1 = __builtin_elementwise_fma(x[k], y1[k], A1);
+                A2 = __builtin_elementwise_fma(x[k], y2[k], A2);
+              }
+              const float a0 = (A0.x + A0.y) + (A0.z + A0.w);
+              const float a1 = (A1.x + A1.y) + (A1.z + A1.w);
+              const float a2 = (A2.x + A2.y) + (A2.z + A2.w);
+              const float g0 = sum_group<LPP>(a0), g1 = sum_group<LPP>(a1), g2 = sum_group<LPP>(a2);
+              if (gl == 0 && el < cn) {
+                gbuf[3 * el] = g0; gbuf[3 * el + 1] = g1; gbuf[3 * el + 2] = g2;
+              }
+            }
           }
-          const float cl = (P.clutter && clu) ? gclu[p] : 0.0f;
-          float v[9];
-          v[0] = L.sv[3 * i0]; v[1] = L.sv[3 * i0 + 1]; v[2] = L.sv[3 * i0 + 2];
-          v[3] = L.sv[3 * i1]; v[4] = L.sv[3 * i1 + 1]; v[5] = L.sv[3 * i1 + 2];
-          v[6] = L.sv[3 * i2]; v[7] = L.sv[3 * i2 + 1]; v[8] = L.sv[3 * i2 + 2];
-          const float g0 = sum_group<LPP>(a0), g1 = sum_group<LPP>(a1), g2 = sum_group<LPP>(a2);
-          const float px = ndc_of(a, Sf), py = ndc_of(b, Sf);
-          const float area = face_area_eps(v, P.keps);
-          const float w0 = edge_fn(px, py, v[3], v[4], v[6], v[7]) / area;
-          const float w1 = edge_fn(px, py, v[6], v[7], v[0], v[1]) / area;
-          const float w2 = edge_fn(px, py, v[0], v[1], v[3], v[4]) / area;
-          float b0 = w0, b1 = w1, b2 = w2, den = 1.0f;
-          if (PERSP) {
-            const float t0 = (w0 * v[5]) * v[8], t1 = (v[2] * w1) * v[8], t2 = (v[2] * v[5]) * w2;
-            den = (t0 + t1) + t2;
-            b0 = t0 / den; b1 = t1 / den; b2 = t2 / den;
-          }
-          const float obj = (b0 * g0 + b1 * g1) + b2 * g2;
-          const bool mine = act && (gl == 0);
-          float ind;
-          if (RAW) {
-            ind = 1.0f;
-          } else if (P.clutter) {
-            loss_sum += mine ? (fmaxf(obj, cl) - fmaxf(0.0f, cl)) : 0.0f;
-            ind = obj > cl ? 1.0f : (obj == cl ? 0.5f : 0.0f);
-          } else {
-            loss_sum += mine ? obj : 0.0f;
-            ind = 1.0f;
-          }
-          if (GRAD) {
-            const float up = mine ? (RAW ? 1.0f : -P.inv_hw * ind) : 0.0f;
-            const float gb0 = up * g0, gb1 = up * g1, gb2 = up * g2;
-            float gw0 = gb0, gw1 = gb1, gw2 = gb2, gz0 = 0.f, gz1 = 0.f, gz2 = 0.f;
+          STAMP(8);
+          // ---------------- phase B
+          if (lane < cn) {
+            const int q = L.list[cb + lane];
+            const int bl = q / bw, al = q - bl * bw;
+            const int a = a_lo + al, b = bb + bl;
+            const int f = (int)zlo[2 * q];
+            const int p = (S - 1 - b - P.r0) * P.w + (S - 1 - a - P.c0);
+            const us4 fv_ = L.fc[f];
+          const int i0 = fv_.x, i1 = fv_.y, i2 = fv_.z;
+            const float cl = (P.clutter && clu) ? gclu[p] : 0.0f;
+            const float g0 = gbuf[3 * lane], g1 = gbuf[3 * lane + 1], g2 = gbuf[3 * lane + 2];
+            float v[9];
+            load_face_verts(L, i0, i1, i2, v);
+            const float px = L.ndc[a], py = L.ndc[b];
+            const float area = face_area_eps(v, P.keps);
+            const float w0 = edge_fn(px, py, v[3], v[4], v[6], v[7]) / area;
+            const float w1 = edge_fn(px, py, v[6], v[7], v[0], v[1]) / area;
+            const float w2 = edge_fn(px, py, v[0], v[1], v[3], v[4]) / area;
+            float b0 = w0, b1 = w1, b2 = w2, den = 1.0f;
             if (PERSP) {
-              const float z0 = v[2], z1 = v[5], z2 = v[8];
-              const float dot = (gb0 * b0 + gb1 * b1) + gb2 * b2;
-              const float gt0 = (gb0 - dot) / den, gt1 = (gb1 - dot) / den, gt2 = (gb2 - dot) / den;
-              gw0 = gt0 * z1 * z2; gw1 = gt1 * z0 * z2; gw2 = gt2 * z0 * z1;
-              gz0 = gt1 * w1 * z2 + gt2 * z1 * w2;
-              gz1 = gt0 * w0 * z2 + gt2 * z0 * w2;
-              gz2 = gt0 * w0 * z1 + gt1 * z0 * w1;
+              const float t0 = (w0 * v[5]) * v[8], t1 = (v[2] * w1) * v[8], t2 = (v[2] * v[5]) * w2;
+              den = (t0 + t1) + t2;
+              b0 = t0 / den; b1 = t1 / den; b2 = t2 / den;
             }
-            const float ia = 1.0f / area;
-            const float gE0 = gw0 * ia, gE1 = gw1 * ia, gE2 = gw2 * ia;
-            const float gA = -((gw0 * w0 + gw1 * w1) + gw2 * w2) * ia;
-            float gv[9];
-            gv[0] = gE1 * (v[7] - py) + gE2 * (py - v[4]) + gA * (v[7] - v[4]);
-            gv[1] = gE1 * (px - v[6]) + gE2 * (v[3] - px) + gA * (v[3] - v[6]);
-            gv[2] = gz0;
-            gv[3] = gE0 * (py - v[7]) + gE2 * (v[1] - py) + gA * (v[1] - v[7]);
-            gv[4] = gE0 * (v[6] - px) + gE2 * (px - v[0]) + gA * (v[6] - v[0]);
-            gv[5] = gz1;
-            gv[6] = gE0 * (v[4] - py) + gE1 * (py - v[1]) + gA * (v[4] - v[1]);
-            gv[7] = gE0 * (px - v[3]) + gE1 * (v[0] - px) + gA * (v[0] - v[3]);
-            gv[8] = gz2;
-            const int vi[3] = {i0, i1, i2};
+            const float obj = (b0 * g0 + b1 * g1) + b2 * g2;
+            float ind;
+            if (RAW) {
+              ind = 1.0f;
+            } else if (P.clutter) {
+              loss_sum += fmaxf(obj, cl) - fmaxf(0.0f, cl);
+              ind = obj > cl ? 1.0f : (obj == cl ? 0.5f : 0.0f);
+            } else {
+              loss_sum += obj;
+              ind = 1.0f;
+            }
+            if (GRAD && ind != 0.0f) {
+              const float up = RAW ? 1.0f : -P.inv_hw * ind;
+              const float gb0 = up * g0, gb1 = up * g1, gb2 = up * g2;
+              float gw0 = gb0, gw1 = gb1, gw2 = gb2, gz0 = 0.f, gz1 = 0.f, gz2 = 0.f;
+              if (PERSP) {
+                const float z0 = v[2], z1 = v[5], z2 = v[8];
+                const float dot = (gb0 * b0 + gb1 * b1) + gb2 * b2;
+                const float gt0 = (gb0 - dot) / den, gt1 = (gb1 - dot) / den, gt2 = (gb2 - dot) / den;
+                gw0 = gt0 * z1 * z2; gw1 = gt1 * z0 * z2; gw2 = gt2 * z0 * z1;
+                gz0 = gt1 * w1 * z2 + gt2 * z1 * w2;
+                gz1 = gt0 * w0 * z2 + gt2 * z0 * w2;
+                gz2 = gt0 * w0 * z1 + gt1 * z0 * w1;
+              }
+              const float ia = 1.0f / area;
+              const float gE0 = gw0 * ia, gE1 = gw1 * ia, gE2 = gw2 * ia;
+              const float gA = -((gw0 * w0 + gw1 * w1) + gw2 * w2) * ia;
+              float gv[9];
+              gv[0] = gE1 * (v[7] - py) + gE2 * (py - v[4]) + gA * (v[7] - v[4]);
+              gv[1] = gE1 * (px - v[6]) + gE2 * (v[3] - px) + gA * (v[3] - v[6]);
+              gv[2] = gz0;
+              gv[3] = gE0 * (py - v[7]) + gE2 * (v[1] - py) + gA * (v[1] - v[7]);
+              gv[4] = gE0 * (v[6] - px) + gE2 * (px - v[0]) + gA * (v[6] - v[0]);
+              gv[5] = gz1;
+              gv[6] = gE0 * (v[4] - py) + gE1 * (py - v[1]) + gA * (v[4] - v[1]);
+              gv[7] = gE0 * (px - v[3]) + gE1 * (v[0] - px) + gA * (v[0] - v[3]);
+              gv[8] = gz2;
+              const int vi[3] = {i0, i1, i2};
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              const float iz = 1.0f / v[3 * c + 2];
-              const float gxc = gv[3 * c] * iz, gyc = gv[3 * c + 1] * iz;
-              const float gzv = gv[3 * c + 2] - (gv[3 * c] * v[3 * c] + gv[3 * c + 1] * v[3 * c + 1]) * iz;
-              const float q0 = s * gxc, q1 = s * gyc, q2 = gzv;
-              const float X0 = L.xw[3 * vi[c]], X1 = L.xw[3 * vi[c] + 1], X2 = L.xw[3 * vi[c] + 2];
-              GR[0] = fmaf(X0, q0, GR[0]); GR[1] = fmaf(X0, q1, GR[1]); GR[2] = fmaf(X0, q2, GR[2]);
-              GR[3] = fmaf(X1, q0, GR[3]); GR[4] = fmaf(X1, q1, GR[4]); GR[5] = fmaf(X1, q2, GR[5]);
-              GR[6] = fmaf(X2, q0, GR[6]); GR[7] = fmaf(X2, q1, GR[7]); GR[8] = fmaf(X2, q2, GR[8]);
-              GT[0] += q0; GT[1] += q1; GT[2] += q2;
+              for (int c = 0; c < 3; ++c) {
+                const float iz = 1.0f / v[3 * c + 2];
+                const float gxc = gv[3 * c] * iz, gyc = gv[3 * c + 1] * iz;
+                const float gzv = gv[3 * c + 2] - (gv[3 * c] * v[3 * c] + gv[3 * c + 1] * v[3 * c + 1]) * iz;
+                const float q0 = s * gxc, q1 = s * gyc, q2 = gzv;
+                const float X0 = gverts[3 * vi[c]], X1 = gverts[3 * vi[c] + 1], X2 = gverts[3 * vi[c] + 2];
+                GR[0] = fmaf(X0, q0, GR[0]); GR[1] = fmaf(X0, q1, GR[1]); GR[2] = fmaf(X0, q2, GR[2]);
+                GR[3] = fmaf(X1, q0, GR[3]); GR[4] = fmaf(X1, q1, GR[4]); GR[5] = fmaf(X1, q2, GR[5]);
+                GR[6] = fmaf(X2, q0, GR[6]); GR[7] = fmaf(X2, q1, GR[7]); GR[8] = fmaf(X2, q2, GR[8]);
+                GT[0] += q0; GT[1] += q1; GT[2] += q2;
+              }
             }
           }
+          STAMP(9);
         }
       }
+      STAMP(4);
       __syncthreads();  // band's z-buffer / lists are reused by the next band
+      STAMP(5);
     }
   }
 
@@ -583,6 +745,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
     for (int i = 0; i < nred; ++i) L.red[wave * RED_N + i] = vals[i];
   }
   __syncthreads();
+  STAMP(6);
 }
 
 // Per-image loss constant: L = K - inv_hw * sum_cov(max(obj,clu) - max(0,clu)),
@@ -605,9 +768,13 @@ __device__ void loss_constant(const KParams &P, const Lds &L, const float *__res
   __syncthreads();
 }
 
-__device__ __forceinline__ void load_world_verts(const Lds &L, const MeshDesc &M) {
-  const gf32p gv = as_global(M.verts);
-  for (int i = threadIdx.x; i < 3 * M.V; i += NT) L.xw[i] = gv[i];
+// Per-kernel LDS set-up: face vertex ids as 8-byte records and the table of pixel-centre
+// NDC coordinates (the exact PixToNdc values, computed once instead of per pixel test).
+__device__ __forceinline__ void load_world_verts(const KParams &P, const Lds &L, const MeshDesc &M) {
+  const gi32p gf = as_global(M.faces);
+  for (int i = threadIdx.x; i < M.F; i += NT)
+    L.fc[i] = us4{(unsigned short)gf[3 * i], (unsigned short)gf[3 * i + 1], (unsigned short)gf[3 * i + 2], 0};
+  for (int i = threadIdx.x; i < P.S; i += NT) L.ndc[i] = ndc_of(i, (float)P.S);
   __syncthreads();
 }
 
@@ -659,7 +826,7 @@ __global__ __launch_bounds__(NT, 4) void raster_kernel(KParams P, const MeshDesc
   }
   if (threadIdx.x < 9) L.ust[U_R + threadIdx.x] = Rs[9 * n + threadIdx.x];
   if (threadIdx.x < 3) L.ust[U_T + threadIdx.x] = Ts[3 * n + threadIdx.x];
-  load_world_verts(L, M);  // ends with a barrier
+  load_world_verts(P, L, M);  // ends with a barrier
   eval_pose<128, PERSP, false, false>(P, L, M, nullptr, nullptr, emit);
 }
 
@@ -676,12 +843,11 @@ __global__ __launch_bounds__(NT, 4) void score_kernel(KParams P, const MeshDesc 
   const float *f = feat + (size_t)img * hw * D;
   const float *c = clu ? clu + (size_t)img * hw : nullptr;
   const Lds L = lds_carve(smem, P);
-  load_world_verts(L, M);
+  load_world_verts(P, L, M);
   loss_constant(P, L, c);
-  Cam cam;
-  float Cp[3] = {0.f, 0.f, 0.f};
   if (threadIdx.x == 0) {
-    Cp[0] = Cs[3 * n]; Cp[1] = Cs[3 * n + 1]; Cp[2] = Cs[3 * n + 2];
+    const float Cp[3] = {Cs[3 * n], Cs[3 * n + 1], Cs[3 * n + 2]};
+    Cam cam;
     ust_set_camera(L, Cp, thetas[n], cam);
   }
   __syncthreads();
@@ -692,6 +858,9 @@ __global__ __launch_bounds__(NT, 4) void score_kernel(KParams P, const MeshDesc 
     const int nc = (int)(block_total(L, 1) + 0.5f);
     if (ncov_out) ncov_out[n] = nc;
     if (grad) {
+      const float Cp[3] = {Cs[3 * n], Cs[3 * n + 1], Cs[3 * n + 2]};
+      Cam cam;
+      dev_camera(Cp, thetas[n], nullptr, cam);  // recomputed rather than kept live across the evaluation
       float g[4];
       ust_totals_to_grad(L, cam, Cp, g);
       grad[4 * n] = g[0]; grad[4 * n + 1] = g[1]; grad[4 * n + 2] = g[2]; grad[4 * n + 3] = g[3];
@@ -719,7 +888,7 @@ __global__ __launch_bounds__(NT, 4) void grid_kernel(KParams P, const MeshDesc *
   const float *f = feat + (size_t)img * hw * D;
   const float *c = clu ? clu + (size_t)img * hw : nullptr;
   const Lds L = lds_carve(smem, P);
-  load_world_verts(L, M);
+  load_world_verts(P, L, M);
   loss_constant(P, L, c);
   if (threadIdx.x == 0) {
     const float *gc = gridC + ((size_t)gi * G + g) * 3;
@@ -770,7 +939,7 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
                                                       const int32_t *mesh_idx, const float *feat, const float *clu,
                                                       const float *C0, const float *theta0, const float *adam_tab,
                                                       int steps, float beta1, float beta2, float eps, float *pose,
-                                                      float *loss_out, float *trace, u64 *counter) {
+                                                      float *loss_out, float *trace, u64 *counter, int stagger) {
   const int n = blockIdx.x;
   const MeshDesc M = meshes[mesh_idx ? mesh_idx[n] : 0];
   const int img = img_idx ? img_idx[n] : n;
@@ -778,7 +947,15 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
   const float *f = feat + (size_t)img * hw * D;
   const float *c = clu ? clu + (size_t)img * hw : nullptr;
   const Lds L = lds_carve(smem, P);
-  load_world_verts(L, M);
+  // One-off start stagger.  Every workgroup does the same amount of work per step, so
+  // without it all resident workgroups run their HBM-heavy score phase at the same time
+  // and their HBM-idle raster phase at the same time; spreading the start over about one
+  // step keeps the chip-wide HBM demand flat for the whole launch.
+  {
+    const unsigned slot = (blockIdx.x * 0x9E3779B1u) >> 25;  // 0..127, well mixed
+    for (unsigned i = 0; i < slot * stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  load_world_verts(P, L, M);
   loss_constant(P, L, c);
   const bool lead = threadIdx.x == 0;
   if (lead) {
@@ -795,6 +972,9 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
   u64 cov_total = 0;
   for (int t = 0; t < steps; ++t) {
     eval_pose<D, PERSP, true, true>(P, L, M, f, c, none);
+#ifdef NEMO_STAMPS
+    const unsigned long long st_lead = (threadIdx.x == 0) ? __builtin_readcyclecounter() : 0ull;
+#endif
     if (lead) {
       float p[4] = {L.ust[U_P], L.ust[U_P + 1], L.ust[U_P + 2], L.ust[U_P + 3]};
       Cam cam;
@@ -822,6 +1002,12 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
       ust_set_camera(L, p, p[3], cam);
     }
     __syncthreads();
+#ifdef NEMO_STAMPS
+    if (threadIdx.x == 0) {
+      const unsigned long long now_ = __builtin_readcyclecounter();
+      atomicAdd(&g_stamps[7], now_ - st_lead);
+    }
+#endif
   }
   if (lead) {
     pose[4 * n] = L.ust[U_P]; pose[4 * n + 1] = L.ust[U_P + 1]; pose[4 * n + 2] = L.ust[U_P + 2];
@@ -845,7 +1031,7 @@ __global__ __launch_bounds__(NT, 4) void interp_bwd_kernel(KParams P, const Mesh
   const size_t hw = (size_t)P.h * P.w;
   if (threadIdx.x < 9) L.ust[U_R + threadIdx.x] = Rs[9 * n + threadIdx.x];
   if (threadIdx.x < 3) L.ust[U_T + threadIdx.x] = Ts[3 * n + threadIdx.x];
-  load_world_verts(L, M);
+  load_world_verts(P, L, M);
   EmitOut none{nullptr, nullptr, nullptr};
   eval_pose<D, PERSP, true, true, true>(P, L, M, grad_out + (size_t)n * hw * D, nullptr, none);
   if (threadIdx.x < 9) grad_R[9 * n + threadIdx.x] = block_total(L, 2 + threadIdx.x);
@@ -928,7 +1114,7 @@ struct nemo_ctx {
   MeshDesc *d_meshes;
   MeshDesc h_meshes[MAX_MESHES];
   int n_meshes;
-  int vmax_seen;
+  int vmax_seen, fmax_seen;
   float *d_adam;
   int adam_steps, adam_cap;
   float beta1, beta2, eps;
@@ -960,17 +1146,20 @@ static int hip_fail(nemo_ctx *ctx, hipError_t e, const char *what) {
 static int plan_lds(nemo_ctx *ctx) {
   const nemo_config &c = ctx->cfg;
   const int vmax = ctx->vmax_seen > 0 ? ((ctx->vmax_seen + 63) & ~63) : 64;
-  long avail = (long)LDS_BUDGET - (long)vmax * 24 - 2L * NW * (c.win_w + 64) - ((NW * RED_N + UST_N) * 4 + 128);
+  const int fmax = ctx->fmax_seen > 0 ? ((ctx->fmax_seen + 63) & ~63) : 64;
+  long avail = (long)LDS_BUDGET - (long)vmax * 16 - (long)fmax * 8 - 2L * NW * (c.win_w + 64) -
+               ((NW * RED_N + UST_N + NW * 64 * 3 + c.raster_size + 4) * 4 + 128);
   long cap = avail / (8 + 2);
   if (cap > (long)c.win_h * c.win_w) cap = (long)c.win_h * c.win_w;
   if (cap > 65535) cap = 65535;  // list entries are 16-bit band-local indices
   if (cap < c.win_w)
     return fail(ctx, NEMO_ERR_UNSUPPORTED,
-                "mesh with %d vertices and window width %d do not fit the %d-byte LDS plan", ctx->vmax_seen,
-                c.win_w, LDS_BUDGET);
+                "mesh with %d vertices / %d faces and window width %d do not fit the %d-byte LDS plan",
+                ctx->vmax_seen, ctx->fmax_seen, c.win_w, LDS_BUDGET);
   ctx->P.cap = (int)cap;
   ctx->P.vmax = vmax;
-  ctx->lds = lds_bytes((int)cap, vmax, c.win_w);
+  ctx->P.fmax = fmax;
+  ctx->lds = lds_bytes((int)cap, vmax, fmax, c.win_w, c.raster_size);
   if (ctx->lds > (size_t)LDS_BUDGET) return fail(ctx, NEMO_ERR_UNSUPPORTED, "LDS plan %zu > budget", ctx->lds);
   return NEMO_OK;
 }
@@ -1045,10 +1234,12 @@ int nemo_mesh_register(nemo_ctx *ctx, const float *d_verts, int32_t V, const int
   if (!d_verts || !d_faces || V <= 0 || F <= 0)
     return fail(ctx, NEMO_ERR_ARG, "nemo_mesh_register: bad mesh (V=%d F=%d)", V, F);
   if (ctx->n_meshes >= MAX_MESHES) return fail(ctx, NEMO_ERR_UNSUPPORTED, "nemo_mesh_register: more than %d meshes", MAX_MESHES);
-  const int old_vmax = ctx->vmax_seen;
+  if (V > 65535) return fail(ctx, NEMO_ERR_UNSUPPORTED, "nemo_mesh_register: %d vertices (16-bit vertex ids in LDS)", V);
+  const int old_vmax = ctx->vmax_seen, old_fmax = ctx->fmax_seen;
   if (V > ctx->vmax_seen) ctx->vmax_seen = V;
+  if (F > ctx->fmax_seen) ctx->fmax_seen = F;
   int rc = plan_lds(ctx);
-  if (rc != NEMO_OK) { ctx->vmax_seen = old_vmax; plan_lds(ctx); return rc; }
+  if (rc != NEMO_OK) { ctx->vmax_seen = old_vmax; ctx->fmax_seen = old_fmax; plan_lds(ctx); return rc; }
   const int id = ctx->n_meshes;
   ctx->h_meshes[id] = MeshDesc{d_verts, d_faces, d_bank, V, F};
   HIP_TRY(ctx, hipMemcpy(ctx->d_meshes + id, &ctx->h_meshes[id], sizeof(MeshDesc), hipMemcpyHostToDevice));
@@ -1167,9 +1358,12 @@ int nemo_solve(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t
   if (ctx->adam_steps <= 0) return fail(ctx, NEMO_ERR_STATE, "nemo_solve: call nemo_set_schedule first");
   if (!d_feat || !d_C0 || !d_theta0 || !d_pose) return fail(ctx, NEMO_ERR_ARG, "nemo_solve: null buffer");
   if (ctx->cfg.clutter && !d_clu) return fail(ctx, NEMO_ERR_ARG, "nemo_solve: clutter loss needs d_clu");
-  if (N == 0) return NEMO_OK;
+  // start stagger in units of (slot x 8128-cycle sleeps): spread ~128 slots over about one step
+  const char *stg = getenv("NEMO_SOLVE_STAGGER");
+  const int stagger = stg ? atoi(stg) : 1;
   DISPATCH_DP(solve_kernel, dim3(N), ctx->P, ctx->d_meshes, d_img_idx, d_mesh_idx, d_feat, d_clu, d_C0, d_theta0,
-              ctx->d_adam, ctx->adam_steps, ctx->beta1, ctx->beta2, ctx->eps, d_pose, d_loss, d_trace, ctx->d_counter);
+              ctx->d_adam, ctx->adam_steps, ctx->beta1, ctx->beta2, ctx->eps, d_pose, d_loss, d_trace, ctx->d_counter,
+              stagger);
   HIP_TRY(ctx, hipGetLastError());
   return NEMO_OK;
 }
@@ -1202,6 +1396,17 @@ int nemo_clutter_score(nemo_ctx *ctx, const float *d_feat, int32_t n_img, const 
   HIP_TRY(ctx, hipGetLastError());
   return NEMO_OK;
 }
+
+#ifdef NEMO_STAMPS
+// diagnostic build only: read (and clear) the per-phase cycle sums
+int nemo_debug_stamps(unsigned long long *out16) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  unsigned long long z[16] = {0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -1;
+  return 0;
+}
+#endif
 
 int64_t nemo_bytes_per_covered_pixel(const nemo_ctx *ctx) { return ctx ? 4LL * ctx->cfg.feat_dim + 4 : 0; }
 

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Solve-only driver for profiling: builds the 12-class workload, runs grid search once, then the
+fused solve `--reps` times.  Used under rocprofv3 (kernel trace / PMC passes)."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nemo_amd.pose_solver import SolverConfig  # noqa: E402
+from nemo_amd.workloads import twelve_class_workload  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--images', type=int, default=512)
+ap.add_argument('--steps', type=int, default=60)
+ap.add_argument('--reps', type=int, default=2)
+ap.add_argument('--grid', action='store_true', help='also time the grid search')
+args = ap.parse_args()
+wl = twelve_class_workload(args.images, seed=1000, cfg=SolverConfig(total_epochs=args.steps))
+s, eng = wl.solver, wl.solver.engine
+clu = eng.clutter_score(wl.feats, wl.clutter)
+C0, th0, _, _ = eng.grid_search(wl.feats, clu, s.grid_C, s.grid_theta, mesh_idx=wl.mesh_idx, grid_idx=wl.mesh_idx)
+torch.cuda.synchronize()
+for r in range(args.reps):
+    if os.environ.get('NEMO_HIP_LIB') and hasattr(eng.lib, 'nemo_debug_stamps'):
+        import ctypes
+        eng.lib.nemo_debug_stamps((ctypes.c_ulonglong * 16)())
+    eng.counter_reset()
+    t0 = time.perf_counter()
+    eng.solve(wl.feats, clu, C0, th0, mesh_idx=wl.mesh_idx)
+    cov = eng.counter_read()
+    dt = time.perf_counter() - t0
+    print(f'solve: {args.images} images x {args.steps} steps: {dt*1e3:.2f} ms, {dt*1e6/args.steps:.1f} us/step, '
+          f'cov/step/img {cov/args.steps/args.images:.0f}, alg GB/s {cov*eng.bytes_per_covered_pixel()/dt/1e9:.0f}')
+if os.environ.get('NEMO_HIP_LIB'):
+    import ctypes
+    st = (ctypes.c_ulonglong * 16)()
+    if hasattr(eng.lib, 'nemo_debug_stamps') and eng.lib.nemo_debug_stamps(st) == 0:
+        names = ['project+bbox', 'zclear', 'raster', 'list', 'score', 'band-barrier', 'reduce', 'lead(adam)']
+        tot = sum(st[:8]) or 1
+        print('score split: phaseA %.1f%% phaseB %.1f%% of total' % (100*st[8]/(tot+st[8]+st[9]-st[4]), 100*st[9]/(tot+st[8]+st[9]-st[4])))
+        print('phase shares (wave-0 cycles, last solve): ' + ', '.join(f'{n} {100*st[i]/tot:.1f}%' for i, n in enumerate(names)))
+if args.grid:
+    for r in range(args.reps):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        eng.grid_search(wl.feats, clu, s.grid_C, s.grid_theta, mesh_idx=wl.mesh_idx, grid_idx=wl.mesh_idx)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(f'grid: {dt*1e3:.2f} ms')
