@@ -93,7 +93,7 @@ def loss_and_grads(cfg, verts, faces, bank, feat, clu, Cpos, theta, p2f_window, 
     else:
         loss = 1.0 - torch.mean(obj)
     loss.backward()
-    out = dict(loss=float(loss), gC=C.grad[0].numpy().copy(), gtheta=float(th.grad[0]),
+    out = dict(loss=float(loss.detach()), gC=C.grad[0].numpy().copy(), gtheta=float(th.grad[0]),
                obj=obj.detach().numpy())
     if ex is not None:
         out['gextra'] = ex.grad[0].numpy().copy()

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Generates the committed fixtures under tests/golden/.  Run in the BUILD container only
+(it reads /root/reference); tests never need the reference.
+
+metric_vectors.npz   PINNED BY THE REFERENCE: outputs of the reference's own
+                     code/lib/ProcessCameraParameters.get_transformation_matrix (imported from
+                     /root/reference; numpy only) on seeded inputs, plus the rotation error of
+                     code/MeshPoseSolveAll.py:31-47 evaluated with those matrices (the script
+                     itself cannot be imported: it parses argv and needs PyTorch3D).
+path_small.npz       PARITY UNPINNED: inputs and outputs of the build's own CPU oracle on a small
+                     scene (the reference has no fixture for the PyTorch3D-backed path and
+                     PyTorch3D cannot run here).  It pins the oracle against silent drift and
+                     gives the GPU tests a fixed vector set.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+
+def metric_vectors():
+    sys.path.insert(0, '/root/reference/code/lib')
+    import ProcessCameraParameters as ref  # the reference's own module
+    from scipy.linalg import logm
+    rng = np.random.default_rng(7)
+    n = 64
+    az = rng.uniform(0, 2 * np.pi, n); el = rng.uniform(-np.pi / 2, np.pi / 2, n)
+    th = rng.uniform(-np.pi, np.pi, n); ds = rng.uniform(0.0, 10.0, n)
+    ds[0] = 0.0  # distance == 0 branch (lib/ProcessCameraParameters.py:130-132)
+    mats = np.stack([ref.get_transformation_matrix(az[i], el[i], ds[i]) for i in range(n)])
+
+    def rot(theta, elev, azum, dis):  # code/MeshPoseSolveAll.py:31-47 with the reference matrix
+        if dis <= 1e-10:
+            dis = 0.5
+        t = np.array([[np.cos(theta), -np.sin(theta), 0], [np.sin(theta), np.cos(theta), 0], [0, 0, 1]])
+        return t @ ref.get_transformation_matrix(azum, elev, dis)[0:3, 0:3]
+
+    errs = []
+    for i in range(0, n, 2):
+        a, b = rot(th[i], el[i], az[i], ds[i]), rot(th[i + 1], el[i + 1], az[i + 1], ds[i + 1])
+        errs.append(np.real(((logm(np.dot(np.transpose(b), a)) ** 2).sum()) ** 0.5 / (2. ** 0.5)))
+    np.savez(os.path.join(HERE, 'metric_vectors.npz'), azimuth=az, elevation=el, theta=th, distance=ds,
+             matrices=mats, pair_errors=np.asarray(errs))
+
+
+def path_small():
+    from nemo_amd import synthetic as syn
+    from oracle import oracle as orc
+    from tests.scenes import make_scene, random_poses
+    sc = make_scene('car', (240, 320), 150, n_img=1, seed=11)
+    rng = np.random.default_rng(12)
+    C, th = random_poses(rng, 4, sc.distance)
+    az, el, t, d = sc.gt[0]
+    C[0] = syn.spherical_to_campos(d * 1.03, el + 0.04, az - 0.05); th[0] = t + 0.03  # near the optimum
+    p2f, bary, loss, grad, ncov = [], [], [], [], []
+    for i in range(4):
+        e = orc.evaluate(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[0], sc.clus[0], C[i], th[i], want_maps=True)
+        p2f.append(e['pix_to_face']); bary.append(e['bary']); loss.append(e['loss'])
+        grad.append(np.r_[e['gC'], e['gtheta']]); ncov.append(e['ncov'])
+    gC, gth = syn.pose_grid(sc.distance)
+    best, glosses = orc.grid_search(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[0], sc.clus[0], gC, gth)
+    tab = syn.adam_table(300)
+    oC, oth, ol, trace = orc.solve(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[0], sc.clus[0], gC[best], gth[best],
+                                   tab, want_trace=True)
+    np.savez_compressed(
+        os.path.join(HERE, 'path_small.npz'),
+        image_hw=np.array([240, 320]), verts=sc.verts, faces=sc.faces, bank=sc.bank.astype(np.float32),
+        cvec=sc.cvec, feat=sc.feats[0], clu=sc.clus[0], gt=sc.gt[0], distance=np.float32(sc.distance),
+        poses_C=C, poses_theta=th, pix_to_face=np.stack(p2f), bary=np.stack(bary), loss=np.asarray(loss, np.float32),
+        grad=np.stack(grad).astype(np.float32), ncov=np.asarray(ncov), grid_losses=glosses, grid_best=best,
+        adam_tab=tab, trace=trace, final_C=oC, final_theta=np.float32(oth), final_loss=np.float32(ol))
+
+
+if __name__ == '__main__':
+    metric_vectors()
+    path_small()
+    for f in ('metric_vectors.npz', 'path_small.npz'):
+        print(f, os.path.getsize(os.path.join(HERE, f)), 'bytes')

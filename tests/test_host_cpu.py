@@ -1,0 +1,115 @@
+"""CPU tier: host logic and the C-ABI surface (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from nemo_amd import synthetic as syn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cuboid_mesh_sizes_and_closedness():
+    v, f = syn.class_mesh('car', 1000)
+    assert v.shape == (1088, 3) and f.shape == (1844, 3)      # V=1088, F=1844
+    assert f.min() == 0 and f.max() == len(v) - 1
+    ex = np.asarray(syn.EXTENTS['car'])
+    assert np.allclose(v.max(0) - v.min(0), ex, atol=1e-6)
+    v2, f2 = syn.class_mesh('car', 10000)
+    assert abs(len(v2) - 10466) < 400 and len(f2) > 19000      # subdivided cuboid of BASELINE config 5
+
+
+def test_cuboid_mesh_matches_reference_construction():
+    """Vertex / face order of tools/CreateCuboidMesh.py:33-108, restated as plain loops."""
+    xr, yr, zr = (-0.2, 0.2), (-0.47, 0.47), (-0.15, 0.15)
+    v, f = syn.cuboid_mesh(xr, yr, zr, 200)
+    w, h, d = 0.4, 0.94, 0.3
+    edge = (((w * h + h * d + w * d) * 2 / (200 * 2)) * 2) ** .5
+    xs = xr[0] + np.linspace(0, w, int(w / edge + 1)); ys = yr[0] + np.linspace(0, h, int(h / edge + 1))
+    zs = zr[0] + np.linspace(0, d, int(d / edge + 1))
+    verts, faces, base = [], [], 0
+    def side(outer, inner, mk):
+        nonlocal base
+        for o in outer:
+            for i in inner:
+                verts.append(mk(o, i))
+        ni = len(inner)
+        for m in range(len(outer) - 1):
+            for n in range(ni - 1):
+                faces.append((base + m * ni + n, base + m * ni + n + 1, base + (m + 1) * ni + n))
+                faces.append((base + (m + 1) * ni + n + 1, base + m * ni + n + 1, base + (m + 1) * ni + n))
+        base += len(outer) * ni
+    side(ys, xs, lambda o, i: (i, o, zs[0])); side(ys, xs, lambda o, i: (i, o, zs[-1]))
+    side(zs, xs, lambda o, i: (i, ys[0], o)); side(zs, xs, lambda o, i: (i, ys[-1], o))
+    side(zs, ys, lambda o, i: (xs[0], i, o)); side(zs, ys, lambda o, i: (xs[-1], i, o))
+    assert np.allclose(v, np.array(verts)) and np.array_equal(f, np.array(faces))
+
+
+def test_pose_grid_order_and_geometry():
+    C, th = syn.pose_grid(5.0)
+    assert C.shape == (144, 3) and th.shape == (144,)
+    # azimuth-major, then elevation, then theta (code/MeshPoseSolveAll.py:66)
+    assert np.allclose(th[:3], np.linspace(-np.pi / 6, np.pi / 6, 3))
+    assert np.allclose(np.linalg.norm(C, axis=1), 5.0, atol=1e-5)
+    assert np.allclose(C[0], [0, 5 * np.sin(-np.pi / 6), 5 * np.cos(-np.pi / 6)], atol=1e-6)
+    g = syn.Geometry.from_image_size((640, 800))
+    assert (g.S, g.h, g.w, g.r0, g.c0) == (100, 80, 100, 10, 0)
+    g = syn.Geometry.from_image_size((256, 672))
+    assert (g.S, g.h, g.w, g.r0, g.c0) == (84, 32, 84, 26, 0)    # car: rows 26..57
+    assert abs(syn.ndc_scale(12.0) - 9.51436) < 1e-4
+
+
+def test_spherical_round_trip():
+    import torch
+    from nemo_amd.pose_solver import camera_position_from_spherical_angles, camera_position_to_spherical_angle
+    rng = np.random.default_rng(0)
+    d = rng.uniform(3, 8, 50); e = rng.uniform(-1.2, 1.2, 50); a = rng.uniform(0, 2 * np.pi, 50)
+    C = camera_position_from_spherical_angles(d, e, a)
+    assert np.allclose(C.numpy(), syn.spherical_to_campos(d, e, a), atol=1e-6)
+    d2, e2, a2 = camera_position_to_spherical_angle(C)
+    assert np.allclose(d2, d, atol=1e-5) and np.allclose(e2, e, atol=1e-5)
+    assert np.allclose(np.mod(a2.numpy() - a + np.pi, 2 * np.pi) - np.pi, 0, atol=1e-5)
+
+
+def test_loss_functions_match_formula():
+    import torch
+    from nemo_amd.pose_solver import loss_fun, loss_fun0, standard_loss_func_with_clutter
+    o, c = torch.rand(8, 9), torch.rand(8, 9)
+    assert torch.allclose(loss_fun(o, c), 1 - (torch.maximum(o, c).mean() - c.mean()))
+    assert torch.allclose(loss_fun0(o), 1 - o.mean())
+    ck = torch.rand(1, 5, 8, 9)
+    assert torch.allclose(standard_loss_func_with_clutter(o[None], ck), loss_fun(o[None], ck.max(1)[0]))
+
+
+def test_abi_library_exports_every_declared_symbol():
+    from nemo_amd import _lib
+    hdr = open(os.path.join(ROOT, 'include', 'nemo_hip.h')).read()
+    declared = sorted(set(re.findall(r'\b(nemo_[A-Za-z_0-9]+)\s*\(', hdr)))
+    assert set(declared) == set(_lib.EXPORTS), (declared, _lib.EXPORTS)
+    assert os.path.exists(_lib.LIB_PATH), 'build with nemo_amd/csrc/build.sh'
+    lib = ctypes.CDLL(_lib.LIB_PATH)  # loads without a GPU; no compute call is made
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert ctypes.sizeof(_lib.NemoConfig) == 48
+
+
+def test_product_path_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'nemo_amd')):
+        for fn in files:
+            if fn.endswith(('.py', '.hip', '.h')):
+                txt = open(os.path.join(dirpath, fn)).read()
+                assert 'from oracle' not in txt and 'import oracle' not in txt and 'libnemo_oracle' not in txt, fn
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from nemo_amd import _lib
+    from nemo_amd.engine import PoseEngine
+    with pytest.raises((_lib.NemoHipError, RuntimeError, AssertionError)):
+        PoseEngine(40, (30, 40), 128)
+    with pytest.raises(_lib.NemoHipError):
+        PoseEngine(40, (30, 40), 128, device='cpu')

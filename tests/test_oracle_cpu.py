@@ -1,0 +1,148 @@
+"""CPU tier (no GPU): the oracle against its pins.
+
+* metric: PINNED by the reference (vectors produced by importing the reference's own
+  lib/ProcessCameraParameters.py, tests/golden/make_golden.py).
+* pose path: PARITY UNPINNED by the reference (no fixtures exist; PyTorch3D not runnable) --
+  the hand-derived backward is checked against torch.autograd on the same op sequence and
+  against central finite differences; Adam against torch.optim.Adam; everything against the
+  committed oracle fixture so the oracle cannot drift silently.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from nemo_amd import synthetic as syn
+from nemo_amd.camera_params import cal_err, cal_rotation_matrix, get_transformation_matrix
+from tests.scenes import make_scene, random_poses
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def test_metric_matches_reference_vectors():
+    g = np.load(os.path.join(GOLD, 'metric_vectors.npz'))
+    for i in range(len(g['azimuth'])):
+        m = get_transformation_matrix(g['azimuth'][i], g['elevation'][i], g['distance'][i])
+        assert np.allclose(m, g['matrices'][i], rtol=0, atol=1e-12)
+    for k, i in enumerate(range(0, len(g['azimuth']), 2)):
+        a = cal_rotation_matrix(g['theta'][i], g['elevation'][i], g['azimuth'][i], g['distance'][i])
+        b = cal_rotation_matrix(g['theta'][i + 1], g['elevation'][i + 1], g['azimuth'][i + 1], g['distance'][i + 1])
+        assert abs(np.real(cal_err(a, b)) - g['pair_errors'][k]) < 1e-9
+
+
+def test_sincos_close_to_libm(oracle):
+    xs = np.concatenate([np.linspace(-7, 7, 4001), np.random.default_rng(0).uniform(-0.6, 0.6, 4000)]).astype(np.float32)
+    for x in xs[::7]:
+        s, c = oracle.sincos(x)
+        assert abs(s - math.sin(float(x))) <= 2.5e-7 and abs(c - math.cos(float(x))) <= 2.5e-7
+
+
+def test_camera_matches_torch_restatement(oracle):
+    import torch
+    from oracle import torch_ref
+    rng = np.random.default_rng(1)
+    C, th = random_poses(rng, 32, 5.0, 0.5)
+    R64, T64 = torch_ref.campos_to_R_T(torch.tensor(C, dtype=torch.float64), torch.tensor(th, dtype=torch.float64))
+    for i in range(32):
+        R, T = oracle.campos_to_R_T(C[i], th[i])
+        assert np.abs(R - R64[i].numpy()).max() < 2e-6 and np.abs(T - T64[i].numpy()).max() < 5e-6
+        assert np.abs(R @ R.T - np.eye(3)).max() < 1e-5
+
+
+def test_raster_invariants(oracle):
+    sc = make_scene(n_img=1)
+    rng = np.random.default_rng(2)
+    C, th = random_poses(rng, 6, sc.distance)
+    for i in range(6):
+        R, T = oracle.campos_to_R_T(C[i], th[i])
+        scr = oracle.project(sc.verts, R, T, sc.cfg.ndc_scale)
+        p2f, bary, zb = oracle.rasterize(sc.cfg, scr, sc.faces)
+        cov = p2f >= 0
+        assert cov.sum() > 50
+        assert np.all(bary[cov] > 0) and np.abs(bary[cov].sum(-1) - 1).max() < 1e-4
+        assert np.all(bary[~cov] == -1) and np.all(p2f[~cov] == -1)
+        assert np.all(zb[cov] > 0)
+        # crop equivalence: the window of the full raster is the cropped output
+        pf, bf, _ = oracle.rasterize(sc.cfg, scr, sc.faces, crop=False)
+        g = sc.geo
+        assert np.array_equal(pf[g.r0:g.r0 + g.h, g.c0:g.c0 + g.w], p2f)
+        # interpolation of a constant bank is constant on covered pixels
+        ones = np.ones_like(sc.bank)
+        out = oracle.interpolate(sc.cfg, p2f, bary, sc.faces, ones)
+        assert np.abs(out[cov] - 1).max() < 1e-4 and np.all(out[~cov] == 0)
+
+
+@pytest.mark.parametrize('persp,clutter', [(False, True), (True, True), (False, False)])
+def test_backward_vs_autograd_and_finite_differences(oracle, persp, clutter):
+    from oracle import torch_ref
+    sc = make_scene(n_img=1, perspective_correct=persp, clutter=clutter)
+    rng = np.random.default_rng(3)
+    C, th = random_poses(rng, 3, sc.distance)
+    az, el, t, d = sc.gt[0]
+    C[0] = syn.spherical_to_campos(d * 1.02, el + 0.03, az - 0.04); th[0] = t + 0.02
+    clu = sc.clus[0] if clutter else None
+    for i in range(3):
+        e = oracle.evaluate(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[0], clu, C[i], th[i], want_maps=True)
+        a = torch_ref.loss_and_grads(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[0], clu, C[i], th[i], e['pix_to_face'])
+        assert abs(e['loss'] - a['loss']) < 1e-6
+        ga = np.r_[a['gC'], a['gtheta']]; go = np.r_[e['gC'], e['gtheta']]
+        assert np.abs(go - ga).max() <= 1e-4 * np.abs(ga).max()
+        # finite differences of the (float64) torch loss with coverage frozen
+        eps = 1e-6
+        for k in range(4):
+            dp = np.zeros(4); dp[k] = eps
+            lp = torch_ref.loss_and_grads(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[0], clu, C[i] + dp[:3], th[i] + dp[3], e['pix_to_face'])['loss']
+            lm = torch_ref.loss_and_grads(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[0], clu, C[i] - dp[:3], th[i] - dp[3], e['pix_to_face'])['loss']
+            fd = (lp - lm) / (2 * eps)
+            assert abs(fd - ga[k]) <= 2e-3 * np.abs(ga).max() + 1e-9
+
+
+def test_extra_trans_gradient(oracle):
+    from oracle import torch_ref
+    sc = make_scene(n_img=1)
+    C, th = random_poses(np.random.default_rng(4), 1, sc.distance)
+    ex = np.array([0.05, -0.03, 0.0], np.float32)
+    e = oracle.evaluate(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[0], sc.clus[0], C[0], th[0], extra=ex, want_maps=True)
+    a = torch_ref.loss_and_grads(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[0], sc.clus[0], C[0], th[0], e['pix_to_face'], extra=ex)
+    assert np.abs(e['gextra'] - a['gextra']).max() <= 1e-4 * np.abs(a['gextra']).max()
+
+
+def test_adam_matches_torch_optim(oracle):
+    from oracle import torch_ref
+    rng = np.random.default_rng(5)
+    grads = rng.normal(0, 1e-2, (300, 4)).astype(np.float32)
+    p0 = np.array([1.0, 2.0, 3.0, 0.1], np.float32)
+    ref = torch_ref.adam_reference(p0, grads)
+    tab = syn.adam_table(300)
+    p, m, v = p0.copy(), np.zeros(4, np.float32), np.zeros(4, np.float32)
+    for t in range(300):
+        p, m, v = oracle.adam_step(p, m, v, grads[t], 0.4, 0.6, tab[t, 0], tab[t, 1])
+        assert np.abs(p - ref[t]).max() <= 2e-6
+    # lr x0.2 after steps 100 and 200 (code/MeshPoseSolveAll.py:249-250)
+    assert abs(tab[100, 0] * (1 - 0.4 ** 101) / (tab[99, 0] * (1 - 0.4 ** 100)) - 0.2) < 1e-6
+
+
+def test_oracle_matches_committed_fixture(oracle):
+    g = np.load(os.path.join(GOLD, 'path_small.npz'))
+    geo = syn.Geometry.from_image_size(tuple(g['image_hw']))
+    cfg = oracle.make_cfg(geo.S, geo.h, geo.w, 128, syn.ndc_scale(12.0), geo.r0, geo.c0)
+    for i in range(4):
+        e = oracle.evaluate(cfg, g['verts'], g['faces'], g['bank'], g['feat'], g['clu'], g['poses_C'][i], g['poses_theta'][i], want_maps=True)
+        assert np.array_equal(e['pix_to_face'], g['pix_to_face'][i]) and np.array_equal(e['bary'], g['bary'][i])
+        assert e['loss'] == g['loss'][i] and e['ncov'] == g['ncov'][i]
+        assert np.array_equal(np.r_[e['gC'], e['gtheta']].astype(np.float32), g['grad'][i])
+    gC, gth = syn.pose_grid(float(g['distance']))
+    best, losses = oracle.grid_search(cfg, g['verts'], g['faces'], g['bank'], g['feat'], g['clu'], gC, gth)
+    assert best == int(g['grid_best']) and np.array_equal(losses, g['grid_losses'])
+    oC, oth, ol, _ = oracle.solve(cfg, g['verts'], g['faces'], g['bank'], g['feat'], g['clu'], gC[best], gth[best], g['adam_tab'])
+    assert np.array_equal(oC, g['final_C']) and np.float32(oth) == g['final_theta']
+
+
+def test_solve_recovers_synthetic_pose(oracle):
+    from nemo_amd.camera_params import pose_error
+    g = np.load(os.path.join(GOLD, 'path_small.npz'))
+    C = g['final_C'].astype(np.float64)
+    dist = np.sqrt((C ** 2).sum()); azim = np.arctan(C[0] / C[2]) % np.pi + np.pi * (C[0] < 0); elev = np.arcsin(C[1] / dist)
+    az, el, th, d = g['gt']
+    assert np.degrees(pose_error((float(g['final_theta']), elev, azim, dist), (th, el, az, d))) < 3.0
