@@ -374,3 +374,44 @@ def test_multicuboid_argmin_over_meshes():
     win = argmin_over_meshes(res, 6, img).cpu().numpy()
     assert win.min() >= 0 and win.max() < 18 and (win // 3 == np.arange(6)).all()   # one winning job per image
     assert ((win % 3) == np.arange(6) // 2).sum() >= 5            # the generating subtype explains its image best
+
+
+def test_reference_style_loop_through_module(oracle):
+    """The reference's own solve loop (code/MeshPoseSolveAll.py:227-250), written against the drop-in
+    MeshInterpolateModule + torch autograd + torch.optim.Adam, tracks the fused solve kernel."""
+    from nemo_amd import mesh_utils as mu
+    from nemo_amd.pose_solver import loss_fun
+    sc = make_scene(n_img=1)
+    S = sc.geo.S
+    cameras = mu.OpenGLPerspectiveCameras(device='cuda:0', fov=12.0)
+    rasterizer = mu.MeshRasterizer(cameras=cameras, raster_settings=mu.RasterizationSettings(
+        image_size=S, blur_radius=0.0, faces_per_pixel=1, bin_size=0))
+    xvert = torch.as_tensor(np.stack([sc.verts[:, 0], -sc.verts[:, 2], sc.verts[:, 1]], 1))  # PASCAL3D+ axes
+    inter_module = mu.MeshInterpolateModule(xvert, torch.as_tensor(sc.faces), torch.as_tensor(sc.bank), rasterizer,
+                                            post_process=mu.center_crop_fun((sc.geo.h, sc.geo.w), (S, S))).cuda()
+    predicted_map = _dev(sc.feats[0]).permute(2, 0, 1).contiguous()      # [D,h,w] like the feature npz
+    clutter_score = _dev(sc.clus[0])
+    gC, gth = syn.pose_grid(sc.distance)
+    eng = _engine(sc)
+    eng.set_schedule(300)
+    C0, th0, _, _ = eng.grid_search(_dev(sc.feats), _dev(sc.clus), _dev(gC[None]), _dev(gth[None]))
+    _, _, trace = eng.solve(_dev(sc.feats), _dev(sc.clus), C0, th0, want_trace=True)
+    trace = trace.cpu().numpy()[0]
+
+    C = torch.nn.Parameter(C0.clone(), requires_grad=True)
+    theta = torch.nn.Parameter(th0.clone(), requires_grad=True)
+    optim = torch.optim.Adam(params=[C, theta], lr=5e-2, betas=(0.4, 0.6))
+    for epoch in range(6):
+        projected_map = inter_module(C, theta).squeeze()
+        assert projected_map.shape == predicted_map.shape
+        object_score = torch.sum(projected_map * predicted_map, dim=0)
+        loss = loss_fun(object_score, clutter_score)
+        loss.backward()
+        g = np.r_[C.grad[0].cpu().numpy(), theta.grad[0].item()]
+        assert abs(loss.item() - trace[epoch, 4]) <= 5e-4 * abs(trace[epoch, 4])
+        assert _relerr(g, trace[epoch, 5:9]) <= 2e-2     # free-running torch loop: poses differ by then ~1e-6
+        if epoch == 0:
+            assert _relerr(g, trace[0, 5:9]) <= 1e-3      # same pose: only torch.cos vs fixed-order cos differ
+        optim.step()
+        optim.zero_grad()
+    assert np.abs(np.r_[C.detach().cpu().numpy()[0], theta.item()] - trace[6, :4]).max() < 5e-3
