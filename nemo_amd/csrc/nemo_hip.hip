@@ -30,14 +30,14 @@
 
 namespace {
 
-constexpr int NT = 512;        // threads per workgroup of the pose kernels
+constexpr int NT = 1024;       // threads per workgroup of the pose kernels (one workgroup per CU)
 constexpr int NW = NT / 64;    // waves per workgroup
 constexpr int RED_N = 16;      // floats per wave in the reduction scratch
 constexpr int UST_N = 32;      // floats of workgroup-uniform state kept in LDS
 // uniform-state slots: R[0..8] T[9..11] p[12..15] m[16..19] v[20..23] K[24]
 constexpr int U_R = 0, U_T = 9, U_P = 12, U_M = 16, U_V = 20, U_K = 24;
 constexpr int MAX_MESHES = 1024;
-constexpr int LDS_BUDGET = 80 * 1024;  // two workgroups per CU (160 KiB LDS)
+constexpr int LDS_BUDGET = 160 * 1024;  // one workgroup per CU owns the whole LDS
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
@@ -307,18 +307,16 @@ struct Lds {
   f4 *sv;                // [vmax] screen verts (u, t, z_view, -)
   us4 *fc;               // [fmax] face vertex ids (i0, i1, i2, -) as 16-bit
   float *ndc;            // [S] pixel-centre NDC coordinate of flipped index a: PixToNdc(a, S)
-  unsigned short *list;  // [NW][list_stride] covered-pixel lists
+  uint32_t *list;        // [cap] covered pixels, face-major: (face id << 16) | window pixel index
   float *red;            // [NW][RED_N]
   float *ust;            // [UST_N] workgroup-uniform state (camera, Adam)
   float *gbuf;           // [NW][64*3] dot products handed from phase A to phase B
-  int list_stride;
 };
 
 __host__ __device__ inline size_t lds_bytes(int cap, int vmax, int fmax, int wmax, int S) {
-  size_t b = (size_t)cap * 8 + (size_t)vmax * 16 + (size_t)fmax * 8;
-  size_t ls = ((size_t)cap / NW + wmax + 63) & ~(size_t)63;
-  b += ls * NW * 2;
+  size_t b = (size_t)cap * 12 + (size_t)vmax * 16 + (size_t)fmax * 8;
   b += (NW * RED_N + UST_N + NW * 64 * 3 + ((S + 3) & ~3)) * 4 + 64;
+  (void)wmax;
   return (b + 15) & ~(size_t)15;
 }
 
@@ -327,9 +325,8 @@ __device__ __forceinline__ Lds lds_carve(unsigned char *base, const KParams &P) 
   L.zb = (u64 *)base;
   L.sv = (f4 *)(base + (size_t)P.cap * 8);
   L.fc = (us4 *)(L.sv + P.vmax);
-  L.list_stride = (P.cap / NW + P.w + 63) & ~63;
-  L.list = (unsigned short *)(L.fc + P.fmax);
-  L.red = (float *)(L.list + (size_t)L.list_stride * NW);
+  L.list = (uint32_t *)(L.fc + P.fmax);
+  L.red = (float *)(L.list + P.cap);
   L.ust = L.red + NW * RED_N;
   L.gbuf = L.ust + UST_N;
   L.ndc = L.gbuf + NW * 64 * 3;
@@ -485,27 +482,25 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       // ---- 2c. face-major list of the covered pixels: ordered by winning face, then
       // row-major.  Thread t owns the contiguous face run [t*fpl, (t+1)*fpl), so a
       // block-wide exclusive scan of the per-thread counts gives every thread its slot
-      // range; the order (hence every later float sum) is deterministic.
+      // range; the order (hence every later float sum) is deterministic.  An entry
+      // packs (face id << 16) | window pixel index, all the score phases need.
       const uint32_t *zlo = (const uint32_t *)L.zb;  // low dword of a key = face id
       const int fpl = (F + NT - 1) / NT;
       const int fbeg = min(F, tid * fpl), fend = min(F, fbeg + fpl);
       auto walk = [&](auto &&visit) {
         for (int f = fbeg; f < fend; ++f) {
           const us4 fv_ = L.fc[f];
-          const int i0 = fv_.x, i1 = fv_.y, i2 = fv_.z;
-          const f4 s0 = L.sv[i0], s1 = L.sv[i1], s2 = L.sv[i2];
+          const f4 s0 = L.sv[fv_.x], s1 = L.sv[fv_.y], s2 = L.sv[fv_.z];
           int fa_lo, fa_hi, fb_lo, fb_hi;
           exact_range(fminf(fminf(s0.x, s1.x), s2.x), fmaxf(fmaxf(s0.x, s1.x), s2.x), a_lo, a_hi, fa_lo, fa_hi);
           exact_range(fminf(fminf(s0.y, s1.y), s2.y), fmaxf(fmaxf(s0.y, s1.y), s2.y), bb, bb + nr - 1, fb_lo, fb_hi);
           for (int b = fb_lo; b <= fb_hi; ++b)
-            for (int a = fa_lo; a <= fa_hi; ++a) {
-              const int q = (b - bb) * bw + (a - a_lo);
-              if (zlo[2 * q] == (uint32_t)f) visit(q);
-            }
+            for (int a = fa_lo; a <= fa_hi; ++a)
+              if (zlo[2 * ((b - bb) * bw + (a - a_lo))] == (uint32_t)f) visit(f, a, b);
         }
       };
       int cnt = 0;
-      walk([&](int) { ++cnt; });
+      walk([&](int, int, int) { ++cnt; });
       int incl = cnt;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
@@ -523,30 +518,31 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
         ntot += t;
       }
       ntot = __builtin_amdgcn_readfirstlane(ntot);
-      walk([&](int q) { L.list[slot++] = (unsigned short)q; });
+      if (cnt > 0)
+        walk([&](int f, int a, int b) {
+          L.list[slot++] = ((uint32_t)f << 16) | (uint32_t)((S - 1 - b - P.r0) * P.w + (S - 1 - a - P.c0));
+        });
       ncov += (tid == 0) ? ntot : 0;
       __syncthreads();
       STAMP(3);
       if (!SCORE) {
         // standalone rasterizer: emit pix_to_face / bary / zbuf for covered pixels
         for (int e = tid; e < ntot; e += NT) {
-          const int q = L.list[e];
-          const int bl = q / bw, al = q - bl * bw;
-          const int a = a_lo + al, b = bb + bl;
-          const int f = (int)zlo[2 * q];
+          const uint32_t ent = L.list[e];
+          const int p = (int)(ent & 0xffffu), f = (int)(ent >> 16);
+          const int i = p / P.w, j = p - i * P.w;
+          const int a = S - 1 - (j + P.c0), b = S - 1 - (i + P.r0);
           const us4 fv_ = L.fc[f];
-          const int i0 = fv_.x, i1 = fv_.y, i2 = fv_.z;
           float v[9];
-          load_face_verts(L, i0, i1, i2, v);
+          load_face_verts(L, fv_.x, fv_.y, fv_.z, v);
           Frag fr;
           fr.b0 = fr.b1 = fr.b2 = fr.pz = -1.0f;
           frag_eval<PERSP>(L.ndc[a], L.ndc[b], v, face_area_eps(v, P.keps), fr);
-          const int p = (S - 1 - b - P.r0) * P.w + (S - 1 - a - P.c0);
           emit.p2f[p] = f;
           emit.bary[3 * p] = fr.b0; emit.bary[3 * p + 1] = fr.b1; emit.bary[3 * p + 2] = fr.b2;
           if (emit.zbuf) emit.zbuf[p] = fr.pz;
         }
-      } else if (ntot > 0) {
+      } else {
         // ---- 3. fused interpolate + score (+ backward).  Each wave owns a contiguous
         // segment of the face-major list and works through it in chunks of 64 pixels:
         //  phase A (LPP lanes per pixel): 16-byte loads of the pixel's feature row and of
@@ -554,6 +550,9 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
         //    DPP, results parked in a wave-private LDS buffer.  A lane group walks
         //    consecutive list entries and re-reads a bank row only when that vertex slot
         //    changes (the two triangles of a cuboid cell share two of their three slots).
+        //    The next entry's feature row is always in flight (ping-pong registers); the
+        //    prefetch is unconditional because a conditional load would make the compiler
+        //    drain vmcnt to zero every iteration.
         //  phase B (one lane per pixel): barycentrics, object score, loss term and the
         //    hand-derived backward to dL/dR, dL/dT accumulators.
         // Both phases are wave-local (LDS operations of one wave complete in order), so
@@ -562,165 +561,169 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
         const int gl = lane & (LPP - 1), grp = lane / LPP;
         float *gbuf = L.gbuf + wave * (64 * 3);
         const int ws_b = (int)(((long long)ntot * wave) / NW), ws_e = (int)(((long long)ntot * (wave + 1)) / NW);
-        auto entry_p = [&](int e) {  // list entry -> window pixel index (row-major in the crop)
-          const int q = L.list[e];
-          const int bl = q / bw, al = q - bl * bw;
-          return (S - 1 - (bb + bl) - P.r0) * P.w + (S - 1 - (a_lo + al) - P.c0);
-        };
-        f4 xn[KIT];  // feature row of this lane group's NEXT entry, always one load ahead
-        {
-          const int cn0 = min(64, ws_e - ws_b), per0 = (cn0 + GPW - 1) / GPW;
-          const gf4p Fp = (gf4p)(gfeat + (size_t)entry_p(ws_b + min(grp * per0, cn0 - 1)) * D) + gl;
-#pragma unroll
-          for (int k = 0; k < KIT; ++k) xn[k] = __builtin_nontemporal_load(Fp + LPP * k);
-        }
-        for (int cb = ws_b; cb < ws_e; cb += 64) {
-          const int cn = min(64, ws_e - cb);
-          const int per = (cn + GPW - 1) / GPW;  // entries per lane group in this chunk
-          // first entry of this group in the next chunk (or a harmless reload at the very end)
-          const int cb2 = cb + 64;
-          const int cn2 = min(64, ws_e - cb2), per2 = (cn2 + GPW - 1) / GPW;
-          const int e_next_chunk = cb2 < ws_e ? cb2 + min(grp * per2, cn2 - 1) : cb + cn - 1;
-          // ---------------- phase A
+        if (ws_e > ws_b) {
+          auto row_ptr = [&](int e) { return (gf4p)(gfeat + (size_t)(L.list[e] & 0xffffu) * D) + gl; };
+          f4 xa[KIT], xb[KIT];  // ping-pong: current / next feature-row fragments
           {
-            int pf = -1, i0 = -1, i1 = -1, i2 = -1;
-            f4 y0[KIT], y1[KIT], y2[KIT];
+            const int cn0 = min(64, ws_e - ws_b), per0 = (cn0 + GPW - 1) / GPW;
+            const gf4p Fp = row_ptr(ws_b + min(grp * per0, cn0 - 1));
 #pragma unroll
-            for (int k = 0; k < KIT; ++k) y0[k] = y1[k] = y2[k] = f4{0.f, 0.f, 0.f, 0.f};
-            for (int j = 0; j < ((NEMO_ABL & 4) ? 0 : per); ++j) {
-              const int el = grp * per + j;
-              const int e = cb + min(el, cn - 1);
-              const int f = (int)zlo[2 * (int)L.list[e]];
-              // 1st: the loads this iteration depends on (bank rows of a changed vertex slot) ...
-              if (f != pf) {
-                pf = f;
-                const us4 fv_ = L.fc[f];
-                const int n0 = fv_.x, n1 = fv_.y, n2 = fv_.z;
-                if (n0 != i0) {
-                  i0 = n0;
-                  const gf4p B = (gf4p)(bank + (size_t)i0 * D) + gl;
-#pragma unroll
-                  for (int k = 0; k < KIT; ++k) y0[k] = (NEMO_ABL & 2) ? f4{(float)i0, 1.f, 2.f, 3.f} : B[LPP * k];
-                }
-                if (n1 != i1) {
-                  i1 = n1;
-                  const gf4p B = (gf4p)(bank + (size_t)i1 * D) + gl;
-#pragma unroll
-                  for (int k = 0; k < KIT; ++k) y1[k] = (NEMO_ABL & 2) ? f4{(float)i1, 1.f, 2.f, 3.f} : B[LPP * k];
-                }
-                if (n2 != i2) {
-                  i2 = n2;
-                  const gf4p B = (gf4p)(bank + (size_t)i2 * D) + gl;
-#pragma unroll
-                  for (int k = 0; k < KIT; ++k) y2[k] = (NEMO_ABL & 2) ? f4{(float)i2, 1.f, 2.f, 3.f} : B[LPP * k];
-                }
-              }
-              // ... 2nd: the next entry's feature row, which stays in flight (vmcnt is in
-              // order) while this entry's dot products wait only for the rows above
-              f4 x[KIT];
-#pragma unroll
-              for (int k = 0; k < KIT; ++k) x[k] = xn[k];
-              {  // unconditional: a conditional load would force a full vmcnt drain every iteration
-                const int en = (j + 1 < per) ? cb + min(el + 1, cn - 1) : e_next_chunk;
-                const gf4p Fp = (gf4p)(gfeat + (size_t)entry_p(en) * D) + gl;
-#pragma unroll
-                for (int k = 0; k < KIT; ++k)
-                  xn[k] = (NEMO_ABL & 1) ? f4{(float)en, 1.f, 2.f, 3.f} : __builtin_nontemporal_load(Fp + LPP * k);
-              }
-              f4 A0 = x[0] * 0.0f, A1 = A0, A2 = A0;
-#pragma unroll
-              for (int k = 0; k < KIT; ++k) {
-                A0 = __builtin_elementwise_fma(x[k], y0[k], A0);
-                A1 = __builtin_elementwise_fma(x[k], y1[k], A1);
-                A2 = __builtin_elementwise_fma(x[k], y2[k], A2);
-              }
-              const float a0 = (A0.x + A0.y) + (A0.z + A0.w);
-              const float a1 = (A1.x + A1.y) + (A1.z + A1.w);
-              const float a2 = (A2.x + A2.y) + (A2.z + A2.w);
-              const float g0 = sum_group<LPP>(a0), g1 = sum_group<LPP>(a1), g2 = sum_group<LPP>(a2);
-              if (gl == 0 && el < cn) {
-                gbuf[3 * el] = g0; gbuf[3 * el + 1] = g1; gbuf[3 * el + 2] = g2;
-              }
-            }
+            for (int k = 0; k < KIT; ++k) xa[k] = __builtin_nontemporal_load(Fp + LPP * k);
           }
-          STAMP(8);
-          // ---------------- phase B
-          if (lane < cn) {
-            const int q = L.list[cb + lane];
-            const int bl = q / bw, al = q - bl * bw;
-            const int a = a_lo + al, b = bb + bl;
-            const int f = (int)zlo[2 * q];
-            const int p = (S - 1 - b - P.r0) * P.w + (S - 1 - a - P.c0);
-            const us4 fv_ = L.fc[f];
-          const int i0 = fv_.x, i1 = fv_.y, i2 = fv_.z;
-            const float cl = (P.clutter && clu) ? gclu[p] : 0.0f;
-            const float g0 = gbuf[3 * lane], g1 = gbuf[3 * lane + 1], g2 = gbuf[3 * lane + 2];
-            float v[9];
-            load_face_verts(L, i0, i1, i2, v);
-            const float px = L.ndc[a], py = L.ndc[b];
-            const float area = face_area_eps(v, P.keps);
-            const float w0 = edge_fn(px, py, v[3], v[4], v[6], v[7]) / area;
-            const float w1 = edge_fn(px, py, v[6], v[7], v[0], v[1]) / area;
-            const float w2 = edge_fn(px, py, v[0], v[1], v[3], v[4]) / area;
-            float b0 = w0, b1 = w1, b2 = w2, den = 1.0f;
-            if (PERSP) {
-              const float t0 = (w0 * v[5]) * v[8], t1 = (v[2] * w1) * v[8], t2 = (v[2] * v[5]) * w2;
-              den = (t0 + t1) + t2;
-              b0 = t0 / den; b1 = t1 / den; b2 = t2 / den;
+          for (int cb = ws_b; cb < ws_e; cb += 64) {
+            const int cn = min(64, ws_e - cb);
+            const int per = (cn + GPW - 1) / GPW;  // entries per lane group in this chunk
+            // first entry of this group in the next chunk (or a harmless reload at the very end)
+            const int cb2 = cb + 64;
+            const int cn2 = min(64, ws_e - cb2), per2 = (cn2 + GPW - 1) / GPW;
+            const int e_next_chunk = cb2 < ws_e ? cb2 + min(grp * per2, cn2 - 1) : cb + cn - 1;
+            // ---------------- phase A
+            {
+              int pf = -1, i0 = -1, i1 = -1, i2 = -1;
+              f4 y0[KIT], y1[KIT], y2[KIT];
+#pragma unroll
+              for (int k = 0; k < KIT; ++k) y0[k] = y1[k] = y2[k] = f4{0.f, 0.f, 0.f, 0.f};
+              auto body = [&](int j, f4(&xc)[KIT], f4(&xnext)[KIT]) {
+                const int el = grp * per + j;
+                const int e = cb + min(el, cn - 1);
+                const int f = (int)(L.list[e] >> 16);
+                // 1st: the loads this entry depends on (bank rows of a changed vertex slot) ...
+                if (f != pf) {
+                  pf = f;
+                  const us4 fv_ = L.fc[f];
+                  const int n0 = fv_.x, n1 = fv_.y, n2 = fv_.z;
+                  if (n0 != i0) {
+                    i0 = n0;
+                    const gf4p B = (gf4p)(bank + (size_t)((NEMO_ABL & 8) ? (i0 & 15) : i0) * D) + gl;
+#pragma unroll
+                    for (int k = 0; k < KIT; ++k) y0[k] = (NEMO_ABL & 2) ? f4{(float)i0, 1.f, 2.f, 3.f} : B[LPP * k];
+                  }
+                  if (n1 != i1) {
+                    i1 = n1;
+                    const gf4p B = (gf4p)(bank + (size_t)((NEMO_ABL & 8) ? (i1 & 15) : i1) * D) + gl;
+#pragma unroll
+                    for (int k = 0; k < KIT; ++k) y1[k] = (NEMO_ABL & 2) ? f4{(float)i1, 1.f, 2.f, 3.f} : B[LPP * k];
+                  }
+                  if (n2 != i2) {
+                    i2 = n2;
+                    const gf4p B = (gf4p)(bank + (size_t)((NEMO_ABL & 8) ? (i2 & 15) : i2) * D) + gl;
+#pragma unroll
+                    for (int k = 0; k < KIT; ++k) y2[k] = (NEMO_ABL & 2) ? f4{(float)i2, 1.f, 2.f, 3.f} : B[LPP * k];
+                  }
+                }
+                // ... 2nd: the next entry's feature row, which stays in flight (vmcnt is in order)
+                {
+                  const int en = (j + 1 < per) ? cb + min(el + 1, cn - 1) : e_next_chunk;
+                  const gf4p Fp = row_ptr(en);
+#pragma unroll
+                  for (int k = 0; k < KIT; ++k)
+                    xnext[k] = (NEMO_ABL & 1) ? f4{(float)en, 1.f, 2.f, 3.f} : __builtin_nontemporal_load(Fp + LPP * k);
+                }
+                f4 A0 = xc[0] * y0[0], A1 = xc[0] * y1[0], A2 = xc[0] * y2[0];
+#pragma unroll
+                for (int k = 1; k < KIT; ++k) {
+                  A0 = __builtin_elementwise_fma(xc[k], y0[k], A0);
+                  A1 = __builtin_elementwise_fma(xc[k], y1[k], A1);
+                  A2 = __builtin_elementwise_fma(xc[k], y2[k], A2);
+                }
+                const float g0 = sum_group<LPP>((A0.x + A0.y) + (A0.z + A0.w));
+                const float g1 = sum_group<LPP>((A1.x + A1.y) + (A1.z + A1.w));
+                const float g2 = sum_group<LPP>((A2.x + A2.y) + (A2.z + A2.w));
+                if (gl == 0 && el < cn) {
+                  gbuf[3 * el] = g0; gbuf[3 * el + 1] = g1; gbuf[3 * el + 2] = g2;
+                }
+              };
+              const int per_run = (NEMO_ABL & 4) ? 0 : per;
+              int j = 0;
+              for (; j + 1 < per_run; j += 2) {
+                body(j, xa, xb);
+                body(j + 1, xb, xa);
+              }
+              if (j < per_run) {  // odd tail: one more entry, then put the prefetched row back in xa
+                body(j, xa, xb);
+#pragma unroll
+                for (int k = 0; k < KIT; ++k) xa[k] = xb[k];
+              }
             }
-            const float obj = (b0 * g0 + b1 * g1) + b2 * g2;
-            float ind;
-            if (RAW) {
-              ind = 1.0f;
-            } else if (P.clutter) {
-              loss_sum += fmaxf(obj, cl) - fmaxf(0.0f, cl);
-              ind = obj > cl ? 1.0f : (obj == cl ? 0.5f : 0.0f);
-            } else {
-              loss_sum += obj;
-              ind = 1.0f;
-            }
-            if (GRAD && ind != 0.0f) {
-              const float up = RAW ? 1.0f : -P.inv_hw * ind;
-              const float gb0 = up * g0, gb1 = up * g1, gb2 = up * g2;
-              float gw0 = gb0, gw1 = gb1, gw2 = gb2, gz0 = 0.f, gz1 = 0.f, gz2 = 0.f;
+            STAMP(8);
+            // ---------------- phase B
+            if (lane < cn) {
+              const uint32_t ent = L.list[cb + lane];
+              const int p = (int)(ent & 0xffffu), f = (int)(ent >> 16);
+              const int pi = p / P.w, pj = p - pi * P.w;
+              const int a = S - 1 - (pj + P.c0), b = S - 1 - (pi + P.r0);
+              const us4 fv_ = L.fc[f];
+              const int i0 = fv_.x, i1 = fv_.y, i2 = fv_.z;
+              const float cl = (P.clutter && clu) ? gclu[p] : 0.0f;
+              const float g0 = gbuf[3 * lane], g1 = gbuf[3 * lane + 1], g2 = gbuf[3 * lane + 2];
+              float v[9];
+              load_face_verts(L, i0, i1, i2, v);
+              const float px = L.ndc[a], py = L.ndc[b];
+              // coverage was decided (exactly) by the rasterizer; the quantities below only feed the
+              // 1e-4-tolerance loss and gradient, so reciprocals replace IEEE divisions here
+              const float ia = __builtin_amdgcn_rcpf(face_area_eps(v, P.keps));
+              const float w0 = edge_fn(px, py, v[3], v[4], v[6], v[7]) * ia;
+              const float w1 = edge_fn(px, py, v[6], v[7], v[0], v[1]) * ia;
+              const float w2 = edge_fn(px, py, v[0], v[1], v[3], v[4]) * ia;
+              float b0 = w0, b1 = w1, b2 = w2, iden = 1.0f;
               if (PERSP) {
-                const float z0 = v[2], z1 = v[5], z2 = v[8];
-                const float dot = (gb0 * b0 + gb1 * b1) + gb2 * b2;
-                const float gt0 = (gb0 - dot) / den, gt1 = (gb1 - dot) / den, gt2 = (gb2 - dot) / den;
-                gw0 = gt0 * z1 * z2; gw1 = gt1 * z0 * z2; gw2 = gt2 * z0 * z1;
-                gz0 = gt1 * w1 * z2 + gt2 * z1 * w2;
-                gz1 = gt0 * w0 * z2 + gt2 * z0 * w2;
-                gz2 = gt0 * w0 * z1 + gt1 * z0 * w1;
+                const float t0 = (w0 * v[5]) * v[8], t1 = (v[2] * w1) * v[8], t2 = (v[2] * v[5]) * w2;
+                iden = __builtin_amdgcn_rcpf((t0 + t1) + t2);
+                b0 = t0 * iden; b1 = t1 * iden; b2 = t2 * iden;
               }
-              const float ia = 1.0f / area;
-              const float gE0 = gw0 * ia, gE1 = gw1 * ia, gE2 = gw2 * ia;
-              const float gA = -((gw0 * w0 + gw1 * w1) + gw2 * w2) * ia;
-              float gv[9];
-              gv[0] = gE1 * (v[7] - py) + gE2 * (py - v[4]) + gA * (v[7] - v[4]);
-              gv[1] = gE1 * (px - v[6]) + gE2 * (v[3] - px) + gA * (v[3] - v[6]);
-              gv[2] = gz0;
-              gv[3] = gE0 * (py - v[7]) + gE2 * (v[1] - py) + gA * (v[1] - v[7]);
-              gv[4] = gE0 * (v[6] - px) + gE2 * (px - v[0]) + gA * (v[6] - v[0]);
-              gv[5] = gz1;
-              gv[6] = gE0 * (v[4] - py) + gE1 * (py - v[1]) + gA * (v[4] - v[1]);
-              gv[7] = gE0 * (px - v[3]) + gE1 * (v[0] - px) + gA * (v[0] - v[3]);
-              gv[8] = gz2;
-              const int vi[3] = {i0, i1, i2};
+              const float obj = (b0 * g0 + b1 * g1) + b2 * g2;
+              float ind;
+              if (RAW) {
+                ind = 1.0f;
+              } else if (P.clutter) {
+                loss_sum += fmaxf(obj, cl) - fmaxf(0.0f, cl);
+                ind = obj > cl ? 1.0f : (obj == cl ? 0.5f : 0.0f);
+              } else {
+                loss_sum += obj;
+                ind = 1.0f;
+              }
+              if (GRAD && ind != 0.0f) {
+                const float up = RAW ? 1.0f : -P.inv_hw * ind;
+                const float gb0 = up * g0, gb1 = up * g1, gb2 = up * g2;
+                float gw0 = gb0, gw1 = gb1, gw2 = gb2, gz0 = 0.f, gz1 = 0.f, gz2 = 0.f;
+                if (PERSP) {
+                  const float z0 = v[2], z1 = v[5], z2 = v[8];
+                  const float dot = (gb0 * b0 + gb1 * b1) + gb2 * b2;
+                  const float gt0 = (gb0 - dot) * iden, gt1 = (gb1 - dot) * iden, gt2 = (gb2 - dot) * iden;
+                  gw0 = gt0 * z1 * z2; gw1 = gt1 * z0 * z2; gw2 = gt2 * z0 * z1;
+                  gz0 = gt1 * w1 * z2 + gt2 * z1 * w2;
+                  gz1 = gt0 * w0 * z2 + gt2 * z0 * w2;
+                  gz2 = gt0 * w0 * z1 + gt1 * z0 * w1;
+                }
+                const float gE0 = gw0 * ia, gE1 = gw1 * ia, gE2 = gw2 * ia;
+                const float gA = -((gw0 * w0 + gw1 * w1) + gw2 * w2) * ia;
+                float gv[9];
+                gv[0] = gE1 * (v[7] - py) + gE2 * (py - v[4]) + gA * (v[7] - v[4]);
+                gv[1] = gE1 * (px - v[6]) + gE2 * (v[3] - px) + gA * (v[3] - v[6]);
+                gv[2] = gz0;
+                gv[3] = gE0 * (py - v[7]) + gE2 * (v[1] - py) + gA * (v[1] - v[7]);
+                gv[4] = gE0 * (v[6] - px) + gE2 * (px - v[0]) + gA * (v[6] - v[0]);
+                gv[5] = gz1;
+                gv[6] = gE0 * (v[4] - py) + gE1 * (py - v[1]) + gA * (v[4] - v[1]);
+                gv[7] = gE0 * (px - v[3]) + gE1 * (v[0] - px) + gA * (v[0] - v[3]);
+                gv[8] = gz2;
+                const int vi[3] = {i0, i1, i2};
 #pragma unroll
-              for (int c = 0; c < 3; ++c) {
-                const float iz = 1.0f / v[3 * c + 2];
-                const float gxc = gv[3 * c] * iz, gyc = gv[3 * c + 1] * iz;
-                const float gzv = gv[3 * c + 2] - (gv[3 * c] * v[3 * c] + gv[3 * c + 1] * v[3 * c + 1]) * iz;
-                const float q0 = s * gxc, q1 = s * gyc, q2 = gzv;
-                const float X0 = gverts[3 * vi[c]], X1 = gverts[3 * vi[c] + 1], X2 = gverts[3 * vi[c] + 2];
-                GR[0] = fmaf(X0, q0, GR[0]); GR[1] = fmaf(X0, q1, GR[1]); GR[2] = fmaf(X0, q2, GR[2]);
-                GR[3] = fmaf(X1, q0, GR[3]); GR[4] = fmaf(X1, q1, GR[4]); GR[5] = fmaf(X1, q2, GR[5]);
-                GR[6] = fmaf(X2, q0, GR[6]); GR[7] = fmaf(X2, q1, GR[7]); GR[8] = fmaf(X2, q2, GR[8]);
-                GT[0] += q0; GT[1] += q1; GT[2] += q2;
+                for (int c = 0; c < 3; ++c) {
+                  const float iz = __builtin_amdgcn_rcpf(v[3 * c + 2]);
+                  const float gxc = gv[3 * c] * iz, gyc = gv[3 * c + 1] * iz;
+                  const float gzv = gv[3 * c + 2] - (gv[3 * c] * v[3 * c] + gv[3 * c + 1] * v[3 * c + 1]) * iz;
+                  const float q0 = s * gxc, q1 = s * gyc, q2 = gzv;
+                  const float X0 = gverts[3 * vi[c]], X1 = gverts[3 * vi[c] + 1], X2 = gverts[3 * vi[c] + 2];
+                  GR[0] = fmaf(X0, q0, GR[0]); GR[1] = fmaf(X0, q1, GR[1]); GR[2] = fmaf(X0, q2, GR[2]);
+                  GR[3] = fmaf(X1, q0, GR[3]); GR[4] = fmaf(X1, q1, GR[4]); GR[5] = fmaf(X1, q2, GR[5]);
+                  GR[6] = fmaf(X2, q0, GR[6]); GR[7] = fmaf(X2, q1, GR[7]); GR[8] = fmaf(X2, q2, GR[8]);
+                  GT[0] += q0; GT[1] += q1; GT[2] += q2;
+                }
               }
             }
+            STAMP(9);
           }
-          STAMP(9);
         }
       }
       STAMP(4);
@@ -1147,11 +1150,12 @@ static int plan_lds(nemo_ctx *ctx) {
   const nemo_config &c = ctx->cfg;
   const int vmax = ctx->vmax_seen > 0 ? ((ctx->vmax_seen + 63) & ~63) : 64;
   const int fmax = ctx->fmax_seen > 0 ? ((ctx->fmax_seen + 63) & ~63) : 64;
-  long avail = (long)LDS_BUDGET - (long)vmax * 16 - (long)fmax * 8 - 2L * NW * (c.win_w + 64) -
+  long avail = (long)LDS_BUDGET - (long)vmax * 16 - (long)fmax * 8 -
                ((NW * RED_N + UST_N + NW * 64 * 3 + c.raster_size + 4) * 4 + 128);
-  long cap = avail / (8 + 2);
+  long cap = avail / (8 + 4);
   if (cap > (long)c.win_h * c.win_w) cap = (long)c.win_h * c.win_w;
-  if (cap > 65535) cap = 65535;  // list entries are 16-bit band-local indices
+  if ((long)c.win_h * c.win_w > 65536)
+    return fail(ctx, NEMO_ERR_UNSUPPORTED, "window %dx%d has more than 65536 pixels (16-bit pixel ids)", c.win_h, c.win_w);
   if (cap < c.win_w)
     return fail(ctx, NEMO_ERR_UNSUPPORTED,
                 "mesh with %d vertices / %d faces and window width %d do not fit the %d-byte LDS plan",
@@ -1234,7 +1238,8 @@ int nemo_mesh_register(nemo_ctx *ctx, const float *d_verts, int32_t V, const int
   if (!d_verts || !d_faces || V <= 0 || F <= 0)
     return fail(ctx, NEMO_ERR_ARG, "nemo_mesh_register: bad mesh (V=%d F=%d)", V, F);
   if (ctx->n_meshes >= MAX_MESHES) return fail(ctx, NEMO_ERR_UNSUPPORTED, "nemo_mesh_register: more than %d meshes", MAX_MESHES);
-  if (V > 65535) return fail(ctx, NEMO_ERR_UNSUPPORTED, "nemo_mesh_register: %d vertices (16-bit vertex ids in LDS)", V);
+  if (V > 65535 || F > 65535)
+    return fail(ctx, NEMO_ERR_UNSUPPORTED, "nemo_mesh_register: V=%d F=%d (vertex and face ids are 16-bit in LDS)", V, F);
   const int old_vmax = ctx->vmax_seen, old_fmax = ctx->fmax_seen;
   if (V > ctx->vmax_seen) ctx->vmax_seen = V;
   if (F > ctx->fmax_seen) ctx->fmax_seen = F;
