@@ -33,9 +33,12 @@ namespace {
 constexpr int NT = 1024;       // threads per workgroup of the pose kernels (one workgroup per CU)
 constexpr int NW = NT / 64;    // waves per workgroup
 constexpr int RED_N = 16;      // floats per wave in the reduction scratch
-constexpr int UST_N = 32;      // floats of workgroup-uniform state kept in LDS
-// uniform-state slots: R[0..8] T[9..11] p[12..15] m[16..19] v[20..23] K[24]
-constexpr int U_R = 0, U_T = 9, U_P = 12, U_M = 16, U_V = 20, U_K = 24;
+constexpr int UST_N = 96;      // floats of workgroup-uniform state kept in LDS
+// uniform-state slots: R[0..8] T[9..11] p[12..15] m[16..19] v[20..23] K[24], chunk counter [25], block totals [32..45],
+// camera intermediates of the current iterate [48..82] (kept for the camera backward)
+constexpr int U_R = 0, U_T = 9, U_P = 12, U_M = 16, U_V = 20, U_K = 24, U_CTR = 25, U_TOT = 32, U_CAM = 48;
+// block totals: [0] loss term, [1..9] dL/dR, [10..12] dL/dT, [13] covered pixels
+constexpr int T_LOSS = 0, T_GR = 1, T_GT = 10, T_NCOV = 13;
 constexpr int MAX_MESHES = 1024;
 constexpr int LDS_BUDGET = 160 * 1024;  // one workgroup per CU owns the whole LDS
 
@@ -67,6 +70,7 @@ struct KParams {
   int cap;   // z-buffer capacity in pixels
   int vmax;  // vertex capacity of the LDS arrays
   int fmax;  // face capacity of the LDS arrays
+  unsigned w_magic;  // floor(2^32 / w) + 1: p / w == umulhi(p, w_magic) for p, w < 2^16
 };
 
 // ---------------------------------------------------------------- small math
@@ -267,6 +271,17 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+// Sum over the 64 lanes with a fixed tree: DPP inside rows of 16, then the four row totals.
+// The result is wave-uniform (built from readlane values).
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = sum8(v);
+  v += dpp_mov<0x140>(v);  // row_mirror
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (r0 + r1) + (r2 + r3);
+}
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o));
@@ -305,6 +320,7 @@ __device__ unsigned long long g_stamps[16];
 struct Lds {
   u64 *zb;               // [cap] packed z-buffer
   f4 *sv;                // [vmax] screen verts (u, t, z_view, -)
+  f4 *xw;                // [vmax] world verts (x, y, z, -)
   us4 *fc;               // [fmax] face vertex ids (i0, i1, i2, -) as 16-bit
   float *ndc;            // [S] pixel-centre NDC coordinate of flipped index a: PixToNdc(a, S)
   uint32_t *list;        // [cap] covered pixels, face-major: (face id << 16) | window pixel index
@@ -314,7 +330,7 @@ struct Lds {
 };
 
 __host__ __device__ inline size_t lds_bytes(int cap, int vmax, int fmax, int wmax, int S) {
-  size_t b = (size_t)cap * 12 + (size_t)vmax * 16 + (size_t)fmax * 8;
+  size_t b = (size_t)cap * 12 + (size_t)vmax * 32 + (size_t)fmax * 8;
   b += (NW * RED_N + UST_N + NW * 64 * 3 + ((S + 3) & ~3)) * 4 + 64;
   (void)wmax;
   return (b + 15) & ~(size_t)15;
@@ -324,7 +340,8 @@ __device__ __forceinline__ Lds lds_carve(unsigned char *base, const KParams &P) 
   Lds L;
   L.zb = (u64 *)base;
   L.sv = (f4 *)(base + (size_t)P.cap * 8);
-  L.fc = (us4 *)(L.sv + P.vmax);
+  L.xw = L.sv + P.vmax;
+  L.fc = (us4 *)(L.xw + P.vmax);
   L.list = (uint32_t *)(L.fc + P.fmax);
   L.red = (float *)(L.list + P.cap);
   L.ust = L.red + NW * RED_N;
@@ -346,14 +363,8 @@ __device__ __forceinline__ void load_face_verts(const Lds &L, int i0, int i1, in
   v[6] = s2.x; v[7] = s2.y; v[8] = s2.z;
 }
 
-// Block totals left in LDS by eval_pose: red[wave][i], i = 0 loss_sum, 1 ncov,
-// 2..10 dL/dR, 11..13 dL/dT.  Summed over waves in a fixed order.
-__device__ __forceinline__ float block_total(const Lds &L, int i) {
-  float t = 0.f;
-#pragma unroll
-  for (int k = 0; k < NW; ++k) t += L.red[k * RED_N + i];
-  return t;
-}
+// Block totals left in LDS by eval_pose (L.ust[U_TOT + i], i = T_LOSS, T_GR.., T_GT.., T_NCOV).
+__device__ __forceinline__ float block_total(const Lds &L, int i) { return L.ust[U_TOT + i]; }
 
 // ---------------------------------------------------------------- the evaluation
 // Whole-workgroup routine.  Camera R (row-major) and T are read from L.ust; the
@@ -371,12 +382,13 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
   const float Sf = (float)S;
   const int V = M.V, F = M.F;
   const float s = P.s;
-  const gf32p gverts = as_global(M.verts);
   const gf32p bank = as_global(M.bank);
   const gf32p gfeat = as_global(feat);
   const gf32p gclu = as_global(clu);
 
   STAMP_DECL;
+  if (tid < 16) L.ust[U_TOT + tid] = 0.0f;  // ordered before any use by the bounding-box barrier
+  if (tid == 16) *(int *)(L.ust + U_CTR) = 0;
   // ---- 1. project vertices (MeshRasterizer.transform; order fixed in DESIGN.md)
   float umin = 3.0e38f, umax = -3.0e38f, tmin = 3.0e38f, tmax = -3.0e38f;
   {
@@ -385,7 +397,8 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
     const float m01 = R[1] * s, m11 = R[4] * s, m21 = R[7] * s, m31 = T[1] * s;
     const float r02 = R[2], r12 = R[5], r22 = R[8], t2 = T[2];
     for (int v = tid; v < V; v += NT) {
-      const float x = gverts[3 * v], y = gverts[3 * v + 1], z = gverts[3 * v + 2];
+      const f4 Xv = L.xw[v];
+      const float x = Xv.x, y = Xv.y, z = Xv.z;
       const float xc = ((x * m00 + y * m10) + z * m20) + m30;
       const float yc = ((x * m01 + y * m11) + z * m21) + m31;
       const float zv = ((x * r02 + y * r12) + z * r22) + t2;
@@ -437,9 +450,6 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
   const bool empty_box = (bw <= 0) || (b_hi < b_lo);
   STAMP(0);
 
-  float loss_sum = 0.f;
-  float GR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  float GT[3] = {0.f, 0.f, 0.f};
   int ncov = 0;
 
   if (!empty_box) {
@@ -530,7 +540,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
         for (int e = tid; e < ntot; e += NT) {
           const uint32_t ent = L.list[e];
           const int p = (int)(ent & 0xffffu), f = (int)(ent >> 16);
-          const int i = p / P.w, j = p - i * P.w;
+          const int i = (int)__umulhi((unsigned)p, P.w_magic), j = p - i * P.w;
           const int a = S - 1 - (j + P.c0), b = S - 1 - (i + P.r0);
           const us4 fv_ = L.fc[f];
           float v[9];
@@ -557,196 +567,229 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
         //    hand-derived backward to dL/dR, dL/dT accumulators.
         // Both phases are wave-local (LDS operations of one wave complete in order), so
         // there is no workgroup barrier inside this loop.
+        // Chunks are handed out dynamically (LDS counter) so that no wave idles at the band barrier;
+        // every chunk leaves its 14 partial sums in LDS (the z-buffer is dead by now and hosts them)
+        // and they are added up in chunk order afterwards, so the totals do not depend on which
+        // wave ran which chunk.
         constexpr int GPW = 64 / LPP;
+        constexpr int NP = GRAD ? 13 : 1;  // partials per chunk: loss term, dL/dR (9), dL/dT (3)
         const int gl = lane & (LPP - 1), grp = lane / LPP;
         float *gbuf = L.gbuf + wave * (64 * 3);
-        const int ws_b = (int)(((long long)ntot * wave) / NW), ws_e = (int)(((long long)ntot * (wave + 1)) / NW);
-        if (ws_e > ws_b) {
-          auto row_ptr = [&](int e) { return (gf4p)(gfeat + (size_t)(L.list[e] & 0xffffu) * D) + gl; };
-          f4 xa[KIT], xb[KIT];  // ping-pong: current / next feature-row fragments
+        float *part = (float *)L.zb;       // [nchunks][16]
+        int *ctr = (int *)(L.ust + U_CTR);
+        const int nchunks = (ntot + 63) >> 6;
+        auto grab = [&]() {
+          int v = 0;
+          if (lane == 0) v = atomicAdd(ctr, 1);
+          return __builtin_amdgcn_readfirstlane(v);
+        };
+        auto row_ptr = [&](int e) { return (gf4p)(gfeat + (size_t)(L.list[e] & 0xffffu) * D) + gl; };
+        auto first_entry = [&](int c) {  // this lane group's first list entry in chunk c
+          const int cn_ = min(64, ntot - c * 64), per_ = (cn_ + GPW - 1) / GPW;
+          return c * 64 + min(grp * per_, cn_ - 1);
+        };
+        int ccur = grab(), cnxt = grab();
+        f4 xa[KIT], xb[KIT];  // ping-pong: current / next feature-row fragments
+        if (ccur < nchunks) {
+          const gf4p Fp = row_ptr(first_entry(ccur));
+#pragma unroll
+          for (int k = 0; k < KIT; ++k) xa[k] = __builtin_nontemporal_load(Fp + LPP * k);
+        }
+        while (ccur < nchunks) {
+          const int cb = ccur * 64;
+          const int cn = min(64, ntot - cb);
+          const int per = (cn + GPW - 1) / GPW;  // entries per lane group in this chunk
+          // first entry of this group in the wave's next chunk (or a harmless reload at the very end)
+          const int e_next_chunk = cnxt < nchunks ? first_entry(cnxt) : cb + cn - 1;
+          // this lane's phase-B pixel: its clutter score is fetched now and lands during phase A
+          const uint32_t ent_b = L.list[cb + min(lane, cn - 1)];
+          const float cl = (P.clutter && clu) ? gclu[ent_b & 0xffffu] : 0.0f;
+          // ---------------- phase A
           {
-            const int cn0 = min(64, ws_e - ws_b), per0 = (cn0 + GPW - 1) / GPW;
-            const gf4p Fp = row_ptr(ws_b + min(grp * per0, cn0 - 1));
+            int pf = -1, i0 = -1, i1 = -1, i2 = -1;
+            f4 y0[KIT], y1[KIT], y2[KIT];
 #pragma unroll
-            for (int k = 0; k < KIT; ++k) xa[k] = __builtin_nontemporal_load(Fp + LPP * k);
-          }
-          for (int cb = ws_b; cb < ws_e; cb += 64) {
-            const int cn = min(64, ws_e - cb);
-            const int per = (cn + GPW - 1) / GPW;  // entries per lane group in this chunk
-            // first entry of this group in the next chunk (or a harmless reload at the very end)
-            const int cb2 = cb + 64;
-            const int cn2 = min(64, ws_e - cb2), per2 = (cn2 + GPW - 1) / GPW;
-            const int e_next_chunk = cb2 < ws_e ? cb2 + min(grp * per2, cn2 - 1) : cb + cn - 1;
-            // ---------------- phase A
-            {
-              int pf = -1, i0 = -1, i1 = -1, i2 = -1;
-              f4 y0[KIT], y1[KIT], y2[KIT];
+            for (int k = 0; k < KIT; ++k) y0[k] = y1[k] = y2[k] = f4{0.f, 0.f, 0.f, 0.f};
+            auto body = [&](int j, f4(&xc)[KIT], f4(&xnext)[KIT]) {
+              const int el = grp * per + j;
+              const int e = cb + min(el, cn - 1);
+              const int f = (int)(L.list[e] >> 16);
+              // 1st: the loads this entry depends on (bank rows of a changed vertex slot) ...
+              if (f != pf) {
+                pf = f;
+                const us4 fv_ = L.fc[f];
+                const int n0 = fv_.x, n1 = fv_.y, n2 = fv_.z;
+                if (n0 != i0) {
+                  i0 = n0;
+                  const gf4p B = (gf4p)(bank + (size_t)i0 * D) + gl;
 #pragma unroll
-              for (int k = 0; k < KIT; ++k) y0[k] = y1[k] = y2[k] = f4{0.f, 0.f, 0.f, 0.f};
-              auto body = [&](int j, f4(&xc)[KIT], f4(&xnext)[KIT]) {
-                const int el = grp * per + j;
-                const int e = cb + min(el, cn - 1);
-                const int f = (int)(L.list[e] >> 16);
-                // 1st: the loads this entry depends on (bank rows of a changed vertex slot) ...
-                if (f != pf) {
-                  pf = f;
-                  const us4 fv_ = L.fc[f];
-                  const int n0 = fv_.x, n1 = fv_.y, n2 = fv_.z;
-                  if (n0 != i0) {
-                    i0 = n0;
-                    const gf4p B = (gf4p)(bank + (size_t)((NEMO_ABL & 8) ? (i0 & 15) : i0) * D) + gl;
-#pragma unroll
-                    for (int k = 0; k < KIT; ++k) y0[k] = (NEMO_ABL & 2) ? f4{(float)i0, 1.f, 2.f, 3.f} : B[LPP * k];
-                  }
-                  if (n1 != i1) {
-                    i1 = n1;
-                    const gf4p B = (gf4p)(bank + (size_t)((NEMO_ABL & 8) ? (i1 & 15) : i1) * D) + gl;
-#pragma unroll
-                    for (int k = 0; k < KIT; ++k) y1[k] = (NEMO_ABL & 2) ? f4{(float)i1, 1.f, 2.f, 3.f} : B[LPP * k];
-                  }
-                  if (n2 != i2) {
-                    i2 = n2;
-                    const gf4p B = (gf4p)(bank + (size_t)((NEMO_ABL & 8) ? (i2 & 15) : i2) * D) + gl;
-#pragma unroll
-                    for (int k = 0; k < KIT; ++k) y2[k] = (NEMO_ABL & 2) ? f4{(float)i2, 1.f, 2.f, 3.f} : B[LPP * k];
-                  }
+                  for (int k = 0; k < KIT; ++k) y0[k] = B[LPP * k];
                 }
-                // ... 2nd: the next entry's feature row, which stays in flight (vmcnt is in order)
-                {
-                  const int en = (j + 1 < per) ? cb + min(el + 1, cn - 1) : e_next_chunk;
-                  const gf4p Fp = row_ptr(en);
+                if (n1 != i1) {
+                  i1 = n1;
+                  const gf4p B = (gf4p)(bank + (size_t)i1 * D) + gl;
 #pragma unroll
-                  for (int k = 0; k < KIT; ++k)
-                    xnext[k] = (NEMO_ABL & 1) ? f4{(float)en, 1.f, 2.f, 3.f} : __builtin_nontemporal_load(Fp + LPP * k);
+                  for (int k = 0; k < KIT; ++k) y1[k] = B[LPP * k];
                 }
-                f4 A0 = xc[0] * y0[0], A1 = xc[0] * y1[0], A2 = xc[0] * y2[0];
+                if (n2 != i2) {
+                  i2 = n2;
+                  const gf4p B = (gf4p)(bank + (size_t)i2 * D) + gl;
 #pragma unroll
-                for (int k = 1; k < KIT; ++k) {
-                  A0 = __builtin_elementwise_fma(xc[k], y0[k], A0);
-                  A1 = __builtin_elementwise_fma(xc[k], y1[k], A1);
-                  A2 = __builtin_elementwise_fma(xc[k], y2[k], A2);
+                  for (int k = 0; k < KIT; ++k) y2[k] = B[LPP * k];
                 }
-                const float g0 = sum_group<LPP>((A0.x + A0.y) + (A0.z + A0.w));
-                const float g1 = sum_group<LPP>((A1.x + A1.y) + (A1.z + A1.w));
-                const float g2 = sum_group<LPP>((A2.x + A2.y) + (A2.z + A2.w));
-                if (gl == 0 && el < cn) {
-                  gbuf[3 * el] = g0; gbuf[3 * el + 1] = g1; gbuf[3 * el + 2] = g2;
-                }
-              };
-              const int per_run = (NEMO_ABL & 4) ? 0 : per;
-              int j = 0;
-              for (; j + 1 < per_run; j += 2) {
-                body(j, xa, xb);
-                body(j + 1, xb, xa);
               }
-              if (j < per_run) {  // odd tail: one more entry, then put the prefetched row back in xa
-                body(j, xa, xb);
+              // ... 2nd: the next entry's feature row, which stays in flight (vmcnt is in order)
+              {
+                const int en = (j + 1 < per) ? cb + min(el + 1, cn - 1) : e_next_chunk;
+                const gf4p Fp = row_ptr(en);
 #pragma unroll
-                for (int k = 0; k < KIT; ++k) xa[k] = xb[k];
+                for (int k = 0; k < KIT; ++k) xnext[k] = __builtin_nontemporal_load(Fp + LPP * k);
               }
+              f4 A0 = xc[0] * y0[0], A1 = xc[0] * y1[0], A2 = xc[0] * y2[0];
+#pragma unroll
+              for (int k = 1; k < KIT; ++k) {
+                A0 = __builtin_elementwise_fma(xc[k], y0[k], A0);
+                A1 = __builtin_elementwise_fma(xc[k], y1[k], A1);
+                A2 = __builtin_elementwise_fma(xc[k], y2[k], A2);
+              }
+              const float g0 = sum_group<LPP>((A0.x + A0.y) + (A0.z + A0.w));
+              const float g1 = sum_group<LPP>((A1.x + A1.y) + (A1.z + A1.w));
+              const float g2 = sum_group<LPP>((A2.x + A2.y) + (A2.z + A2.w));
+              if (gl == 0 && el < cn) {
+                gbuf[3 * el] = g0; gbuf[3 * el + 1] = g1; gbuf[3 * el + 2] = g2;
+              }
+            };
+            int j = 0;
+            for (; j + 1 < per; j += 2) {
+              body(j, xa, xb);
+              body(j + 1, xb, xa);
             }
-            STAMP(8);
-            // ---------------- phase B
-            if (lane < cn) {
-              const uint32_t ent = L.list[cb + lane];
-              const int p = (int)(ent & 0xffffu), f = (int)(ent >> 16);
-              const int pi = p / P.w, pj = p - pi * P.w;
-              const int a = S - 1 - (pj + P.c0), b = S - 1 - (pi + P.r0);
-              const us4 fv_ = L.fc[f];
-              const int i0 = fv_.x, i1 = fv_.y, i2 = fv_.z;
-              const float cl = (P.clutter && clu) ? gclu[p] : 0.0f;
-              const float g0 = gbuf[3 * lane], g1 = gbuf[3 * lane + 1], g2 = gbuf[3 * lane + 2];
-              float v[9];
-              load_face_verts(L, i0, i1, i2, v);
-              const float px = L.ndc[a], py = L.ndc[b];
-              // coverage was decided (exactly) by the rasterizer; the quantities below only feed the
-              // 1e-4-tolerance loss and gradient, so reciprocals replace IEEE divisions here
-              const float ia = __builtin_amdgcn_rcpf(face_area_eps(v, P.keps));
-              const float w0 = edge_fn(px, py, v[3], v[4], v[6], v[7]) * ia;
-              const float w1 = edge_fn(px, py, v[6], v[7], v[0], v[1]) * ia;
-              const float w2 = edge_fn(px, py, v[0], v[1], v[3], v[4]) * ia;
-              float b0 = w0, b1 = w1, b2 = w2, iden = 1.0f;
+            if (j < per) {  // odd tail: one more entry, then put the prefetched row back in xa
+              body(j, xa, xb);
+#pragma unroll
+              for (int k = 0; k < KIT; ++k) xa[k] = xb[k];
+            }
+          }
+          STAMP(8);
+          // ---------------- phase B: this lane's pixel -> its 13 contributions
+          float pl = 0.f;
+          float GR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          float GT[3] = {0.f, 0.f, 0.f};
+          if (lane < cn) {
+            const int p = (int)(ent_b & 0xffffu), f = (int)(ent_b >> 16);
+            const int pi = (int)__umulhi((unsigned)p, P.w_magic), pj = p - pi * P.w;
+            const int a = S - 1 - (pj + P.c0), b = S - 1 - (pi + P.r0);
+            const us4 fv_ = L.fc[f];
+            const int i0 = fv_.x, i1 = fv_.y, i2 = fv_.z;
+            const float g0 = gbuf[3 * lane], g1 = gbuf[3 * lane + 1], g2 = gbuf[3 * lane + 2];
+            float v[9];
+            load_face_verts(L, i0, i1, i2, v);
+            const float px = L.ndc[a], py = L.ndc[b];
+            // coverage was decided (exactly) by the rasterizer; the quantities below only feed the
+            // 1e-4-tolerance loss and gradient, so reciprocals replace IEEE divisions here
+            const float ia = __builtin_amdgcn_rcpf(face_area_eps(v, P.keps));
+            const float w0 = edge_fn(px, py, v[3], v[4], v[6], v[7]) * ia;
+            const float w1 = edge_fn(px, py, v[6], v[7], v[0], v[1]) * ia;
+            const float w2 = edge_fn(px, py, v[0], v[1], v[3], v[4]) * ia;
+            float b0 = w0, b1 = w1, b2 = w2, iden = 1.0f;
+            if (PERSP) {
+              const float t0 = (w0 * v[5]) * v[8], t1 = (v[2] * w1) * v[8], t2 = (v[2] * v[5]) * w2;
+              iden = __builtin_amdgcn_rcpf((t0 + t1) + t2);
+              b0 = t0 * iden; b1 = t1 * iden; b2 = t2 * iden;
+            }
+            const float obj = (b0 * g0 + b1 * g1) + b2 * g2;
+            float ind;
+            if (RAW) {
+              ind = 1.0f;
+            } else if (P.clutter) {
+              pl = fmaxf(obj, cl) - fmaxf(0.0f, cl);
+              ind = obj > cl ? 1.0f : (obj == cl ? 0.5f : 0.0f);
+            } else {
+              pl = obj;
+              ind = 1.0f;
+            }
+            if (GRAD && ind != 0.0f) {
+              const float up = RAW ? 1.0f : -P.inv_hw * ind;
+              const float gb0 = up * g0, gb1 = up * g1, gb2 = up * g2;
+              float gw0 = gb0, gw1 = gb1, gw2 = gb2, gz0 = 0.f, gz1 = 0.f, gz2 = 0.f;
               if (PERSP) {
-                const float t0 = (w0 * v[5]) * v[8], t1 = (v[2] * w1) * v[8], t2 = (v[2] * v[5]) * w2;
-                iden = __builtin_amdgcn_rcpf((t0 + t1) + t2);
-                b0 = t0 * iden; b1 = t1 * iden; b2 = t2 * iden;
+                const float z0 = v[2], z1 = v[5], z2 = v[8];
+                const float dot = (gb0 * b0 + gb1 * b1) + gb2 * b2;
+                const float gt0 = (gb0 - dot) * iden, gt1 = (gb1 - dot) * iden, gt2 = (gb2 - dot) * iden;
+                gw0 = gt0 * z1 * z2; gw1 = gt1 * z0 * z2; gw2 = gt2 * z0 * z1;
+                gz0 = gt1 * w1 * z2 + gt2 * z1 * w2;
+                gz1 = gt0 * w0 * z2 + gt2 * z0 * w2;
+                gz2 = gt0 * w0 * z1 + gt1 * z0 * w1;
               }
-              const float obj = (b0 * g0 + b1 * g1) + b2 * g2;
-              float ind;
-              if (RAW) {
-                ind = 1.0f;
-              } else if (P.clutter) {
-                loss_sum += fmaxf(obj, cl) - fmaxf(0.0f, cl);
-                ind = obj > cl ? 1.0f : (obj == cl ? 0.5f : 0.0f);
-              } else {
-                loss_sum += obj;
-                ind = 1.0f;
-              }
-              if (GRAD && ind != 0.0f) {
-                const float up = RAW ? 1.0f : -P.inv_hw * ind;
-                const float gb0 = up * g0, gb1 = up * g1, gb2 = up * g2;
-                float gw0 = gb0, gw1 = gb1, gw2 = gb2, gz0 = 0.f, gz1 = 0.f, gz2 = 0.f;
-                if (PERSP) {
-                  const float z0 = v[2], z1 = v[5], z2 = v[8];
-                  const float dot = (gb0 * b0 + gb1 * b1) + gb2 * b2;
-                  const float gt0 = (gb0 - dot) * iden, gt1 = (gb1 - dot) * iden, gt2 = (gb2 - dot) * iden;
-                  gw0 = gt0 * z1 * z2; gw1 = gt1 * z0 * z2; gw2 = gt2 * z0 * z1;
-                  gz0 = gt1 * w1 * z2 + gt2 * z1 * w2;
-                  gz1 = gt0 * w0 * z2 + gt2 * z0 * w2;
-                  gz2 = gt0 * w0 * z1 + gt1 * z0 * w1;
-                }
-                const float gE0 = gw0 * ia, gE1 = gw1 * ia, gE2 = gw2 * ia;
-                const float gA = -((gw0 * w0 + gw1 * w1) + gw2 * w2) * ia;
-                float gv[9];
-                gv[0] = gE1 * (v[7] - py) + gE2 * (py - v[4]) + gA * (v[7] - v[4]);
-                gv[1] = gE1 * (px - v[6]) + gE2 * (v[3] - px) + gA * (v[3] - v[6]);
-                gv[2] = gz0;
-                gv[3] = gE0 * (py - v[7]) + gE2 * (v[1] - py) + gA * (v[1] - v[7]);
-                gv[4] = gE0 * (v[6] - px) + gE2 * (px - v[0]) + gA * (v[6] - v[0]);
-                gv[5] = gz1;
-                gv[6] = gE0 * (v[4] - py) + gE1 * (py - v[1]) + gA * (v[4] - v[1]);
-                gv[7] = gE0 * (px - v[3]) + gE1 * (v[0] - px) + gA * (v[0] - v[3]);
-                gv[8] = gz2;
-                const int vi[3] = {i0, i1, i2};
+              const float gE0 = gw0 * ia, gE1 = gw1 * ia, gE2 = gw2 * ia;
+              const float gA = -((gw0 * w0 + gw1 * w1) + gw2 * w2) * ia;
+              float gv[9];
+              gv[0] = gE1 * (v[7] - py) + gE2 * (py - v[4]) + gA * (v[7] - v[4]);
+              gv[1] = gE1 * (px - v[6]) + gE2 * (v[3] - px) + gA * (v[3] - v[6]);
+              gv[2] = gz0;
+              gv[3] = gE0 * (py - v[7]) + gE2 * (v[1] - py) + gA * (v[1] - v[7]);
+              gv[4] = gE0 * (v[6] - px) + gE2 * (px - v[0]) + gA * (v[6] - v[0]);
+              gv[5] = gz1;
+              gv[6] = gE0 * (v[4] - py) + gE1 * (py - v[1]) + gA * (v[4] - v[1]);
+              gv[7] = gE0 * (px - v[3]) + gE1 * (v[0] - px) + gA * (v[0] - v[3]);
+              gv[8] = gz2;
+              const int vi[3] = {i0, i1, i2};
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                  const float iz = __builtin_amdgcn_rcpf(v[3 * c + 2]);
-                  const float gxc = gv[3 * c] * iz, gyc = gv[3 * c + 1] * iz;
-                  const float gzv = gv[3 * c + 2] - (gv[3 * c] * v[3 * c] + gv[3 * c + 1] * v[3 * c + 1]) * iz;
-                  const float q0 = s * gxc, q1 = s * gyc, q2 = gzv;
-                  const float X0 = gverts[3 * vi[c]], X1 = gverts[3 * vi[c] + 1], X2 = gverts[3 * vi[c] + 2];
-                  GR[0] = fmaf(X0, q0, GR[0]); GR[1] = fmaf(X0, q1, GR[1]); GR[2] = fmaf(X0, q2, GR[2]);
-                  GR[3] = fmaf(X1, q0, GR[3]); GR[4] = fmaf(X1, q1, GR[4]); GR[5] = fmaf(X1, q2, GR[5]);
-                  GR[6] = fmaf(X2, q0, GR[6]); GR[7] = fmaf(X2, q1, GR[7]); GR[8] = fmaf(X2, q2, GR[8]);
-                  GT[0] += q0; GT[1] += q1; GT[2] += q2;
-                }
+              for (int c = 0; c < 3; ++c) {
+                const float iz = __builtin_amdgcn_rcpf(v[3 * c + 2]);
+                const float gxc = gv[3 * c] * iz, gyc = gv[3 * c + 1] * iz;
+                const float gzv = gv[3 * c + 2] - (gv[3 * c] * v[3 * c] + gv[3 * c + 1] * v[3 * c + 1]) * iz;
+                const float q0 = s * gxc, q1 = s * gyc, q2 = gzv;
+                const f4 Xw = L.xw[vi[c]];
+                const float X0 = Xw.x, X1 = Xw.y, X2 = Xw.z;
+                GR[0] = fmaf(X0, q0, GR[0]); GR[1] = fmaf(X0, q1, GR[1]); GR[2] = fmaf(X0, q2, GR[2]);
+                GR[3] = fmaf(X1, q0, GR[3]); GR[4] = fmaf(X1, q1, GR[4]); GR[5] = fmaf(X1, q2, GR[5]);
+                GR[6] = fmaf(X2, q0, GR[6]); GR[7] = fmaf(X2, q1, GR[7]); GR[8] = fmaf(X2, q2, GR[8]);
+                GT[0] += q0; GT[1] += q1; GT[2] += q2;
               }
             }
-            STAMP(9);
           }
+          // chunk partials (fixed DPP tree), written by one lane
+          {
+            float pv[13];
+            pv[0] = wave_sum_dpp(pl);
+            if (GRAD) {
+#pragma unroll
+              for (int i = 0; i < 9; ++i) pv[1 + i] = wave_sum_dpp(GR[i]);
+#pragma unroll
+              for (int i = 0; i < 3; ++i) pv[10 + i] = wave_sum_dpp(GT[i]);
+            }
+            if (lane == 0) {
+#pragma unroll
+              for (int i = 0; i < NP; ++i) part[ccur * 16 + i] = pv[i];
+            }
+          }
+          STAMP(9);
+          ccur = cnxt;
+          cnxt = grab();
         }
       }
       STAMP(4);
+      __syncthreads();  // all chunks of the band are done
+      if (SCORE) {
+        // chunk partials -> running totals, in chunk order, one lane per total (wave 0 owns U_TOT)
+        constexpr int NPB = GRAD ? 13 : 1;
+        if (wave == 0 && lane < NPB) {
+          const float *part = (const float *)L.zb;
+          const int nchunks = (ntot + 63) >> 6;
+          float t = L.ust[U_TOT + lane];
+          for (int c = 0; c < nchunks; ++c) t += part[c * 16 + lane];
+          L.ust[U_TOT + lane] = t;
+        }
+        if (tid == 0) *(int *)(L.ust + U_CTR) = 0;
+      }
       __syncthreads();  // band's z-buffer / lists are reused by the next band
       STAMP(5);
     }
   }
 
-  // ---- 4. deterministic reduction: wave totals -> L.red (summed by block_total)
-  float vals[14];
-  vals[0] = loss_sum; vals[1] = (float)ncov;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) vals[2 + i] = GR[i];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) vals[11 + i] = GT[i];
-  constexpr int nred = GRAD ? 14 : 2;
-#pragma unroll
-  for (int i = 0; i < nred; ++i) vals[i] = wave_sum(vals[i]);
-  __syncthreads();  // red[] was used for the bounding box
-  if (lane == 0) {
-#pragma unroll
-    for (int i = 0; i < nred; ++i) L.red[wave * RED_N + i] = vals[i];
-  }
+  // ---- 4. totals are already in L.ust[U_TOT..] (chunk partials added in chunk order by wave 0)
+  if (tid == 0) L.ust[U_TOT + T_NCOV] = (float)ncov;
   __syncthreads();
   STAMP(6);
 }
@@ -767,7 +810,12 @@ __device__ void loss_constant(const KParams &P, const Lds &L, const float *__res
   float d = wave_sum((float)a);
   if (lane == 0) L.red[wave * RED_N] = d;
   __syncthreads();
-  if (tid == 0) L.ust[U_K] = 1.0f + block_total(L, 0) * P.inv_hw;
+  if (tid == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) t += L.red[k * RED_N];
+    L.ust[U_K] = 1.0f + t * P.inv_hw;
+  }
   __syncthreads();
 }
 
@@ -775,6 +823,8 @@ __device__ void loss_constant(const KParams &P, const Lds &L, const float *__res
 // NDC coordinates (the exact PixToNdc values, computed once instead of per pixel test).
 __device__ __forceinline__ void load_world_verts(const KParams &P, const Lds &L, const MeshDesc &M) {
   const gi32p gf = as_global(M.faces);
+  const gf32p gv = as_global(M.verts);
+  for (int i = threadIdx.x; i < M.V; i += NT) L.xw[i] = f4{gv[3 * i], gv[3 * i + 1], gv[3 * i + 2], 0.0f};
   for (int i = threadIdx.x; i < M.F; i += NT)
     L.fc[i] = us4{(unsigned short)gf[3 * i], (unsigned short)gf[3 * i + 1], (unsigned short)gf[3 * i + 2], 0};
   for (int i = threadIdx.x; i < P.S; i += NT) L.ndc[i] = ndc_of(i, (float)P.S);
@@ -782,19 +832,28 @@ __device__ __forceinline__ void load_world_verts(const KParams &P, const Lds &L,
 }
 
 // Thread-0 helpers working on the uniform state in LDS.
+static_assert(sizeof(Cam) == 35 * sizeof(float) && U_CAM + 35 <= UST_N, "camera slot");
 __device__ __forceinline__ void ust_set_camera(const Lds &L, const float *Cp, float theta, Cam &cam) {
   dev_camera(Cp, theta, nullptr, cam);
 #pragma unroll
   for (int i = 0; i < 9; ++i) L.ust[U_R + i] = cam.R[i];
 #pragma unroll
   for (int i = 0; i < 3; ++i) L.ust[U_T + i] = cam.T[i];
+  const float *cf = (const float *)&cam;  // kept for the camera backward of this iterate
+#pragma unroll
+  for (int i = 0; i < 35; ++i) L.ust[U_CAM + i] = cf[i];
+}
+__device__ __forceinline__ void ust_get_camera(const Lds &L, Cam &cam) {
+  float *cf = (float *)&cam;
+#pragma unroll
+  for (int i = 0; i < 35; ++i) cf[i] = L.ust[U_CAM + i];
 }
 __device__ __forceinline__ void ust_totals_to_grad(const Lds &L, const Cam &cam, const float *Cp, float g[4]) {
   float GR[9], GT[3];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) GR[i] = block_total(L, 2 + i);
+  for (int i = 0; i < 9; ++i) GR[i] = block_total(L, T_GR + i);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) GT[i] = block_total(L, 11 + i);
+  for (int i = 0; i < 3; ++i) GT[i] = block_total(L, T_GT + i);
   dev_camera_bwd(cam, Cp, GR, GT, g, g[3]);
 }
 
@@ -858,12 +917,12 @@ __global__ __launch_bounds__(NT, 4) void score_kernel(KParams P, const MeshDesc 
   eval_pose<D, PERSP, true, true>(P, L, M, f, c, none);
   if (threadIdx.x == 0) {
     loss[n] = L.ust[U_K] - P.inv_hw * block_total(L, 0);
-    const int nc = (int)(block_total(L, 1) + 0.5f);
+    const int nc = (int)(block_total(L, T_NCOV) + 0.5f);
     if (ncov_out) ncov_out[n] = nc;
     if (grad) {
       const float Cp[3] = {Cs[3 * n], Cs[3 * n + 1], Cs[3 * n + 2]};
       Cam cam;
-      dev_camera(Cp, thetas[n], nullptr, cam);  // recomputed rather than kept live across the evaluation
+      ust_get_camera(L, cam);
       float g[4];
       ust_totals_to_grad(L, cam, Cp, g);
       grad[4 * n] = g[0]; grad[4 * n + 1] = g[1]; grad[4 * n + 2] = g[2]; grad[4 * n + 3] = g[3];
@@ -904,7 +963,7 @@ __global__ __launch_bounds__(NT, 4) void grid_kernel(KParams P, const MeshDesc *
   eval_pose<D, PERSP, false, true>(P, L, M, f, c, none);
   if (threadIdx.x == 0) {
     losses[(size_t)n * G + g] = L.ust[U_K] - P.inv_hw * block_total(L, 0);
-    if (counter) atomicAdd(counter, (u64)(block_total(L, 1) + 0.5f));
+    if (counter) atomicAdd(counter, (u64)(block_total(L, T_NCOV) + 0.5f));
   }
 }
 
@@ -981,11 +1040,11 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
     if (lead) {
       float p[4] = {L.ust[U_P], L.ust[U_P + 1], L.ust[U_P + 2], L.ust[U_P + 3]};
       Cam cam;
-      dev_camera(p, p[3], nullptr, cam);  // recomputed rather than kept live across the evaluation
+      ust_get_camera(L, cam);
       float g[4];
       ust_totals_to_grad(L, cam, p, g);
       last_loss = L.ust[U_K] - P.inv_hw * block_total(L, 0);
-      cov_total += (u64)(block_total(L, 1) + 0.5f);
+      cov_total += (u64)(block_total(L, T_NCOV) + 0.5f);
       if (trace) {
         float *tr = trace + ((size_t)n * steps + t) * 9;
         tr[0] = p[0]; tr[1] = p[1]; tr[2] = p[2]; tr[3] = p[3]; tr[4] = last_loss;
@@ -1037,8 +1096,8 @@ __global__ __launch_bounds__(NT, 4) void interp_bwd_kernel(KParams P, const Mesh
   load_world_verts(P, L, M);
   EmitOut none{nullptr, nullptr, nullptr};
   eval_pose<D, PERSP, true, true, true>(P, L, M, grad_out + (size_t)n * hw * D, nullptr, none);
-  if (threadIdx.x < 9) grad_R[9 * n + threadIdx.x] = block_total(L, 2 + threadIdx.x);
-  if (threadIdx.x < 3) grad_T[3 * n + threadIdx.x] = block_total(L, 11 + threadIdx.x);
+  if (threadIdx.x < 9) grad_R[9 * n + threadIdx.x] = block_total(L, T_GR + threadIdx.x);
+  if (threadIdx.x < 3) grad_T[3 * n + threadIdx.x] = block_total(L, T_GT + threadIdx.x);
 }
 
 // Clutter score: out[p] = max_k <cbank[k], feat[p]> (code/MeshPoseSolveAll.py:220,
@@ -1150,7 +1209,7 @@ static int plan_lds(nemo_ctx *ctx) {
   const nemo_config &c = ctx->cfg;
   const int vmax = ctx->vmax_seen > 0 ? ((ctx->vmax_seen + 63) & ~63) : 64;
   const int fmax = ctx->fmax_seen > 0 ? ((ctx->fmax_seen + 63) & ~63) : 64;
-  long avail = (long)LDS_BUDGET - (long)vmax * 16 - (long)fmax * 8 -
+  long avail = (long)LDS_BUDGET - (long)vmax * 32 - (long)fmax * 8 -
                ((NW * RED_N + UST_N + NW * 64 * 3 + c.raster_size + 4) * 4 + 128);
   long cap = avail / (8 + 4);
   if (cap > (long)c.win_h * c.win_w) cap = (long)c.win_h * c.win_w;
@@ -1163,6 +1222,7 @@ static int plan_lds(nemo_ctx *ctx) {
   ctx->P.cap = (int)cap;
   ctx->P.vmax = vmax;
   ctx->P.fmax = fmax;
+  ctx->P.w_magic = (unsigned)(0x100000000ULL / (unsigned long long)c.win_w) + 1u;
   ctx->lds = lds_bytes((int)cap, vmax, fmax, c.win_w, c.raster_size);
   if (ctx->lds > (size_t)LDS_BUDGET) return fail(ctx, NEMO_ERR_UNSUPPORTED, "LDS plan %zu > budget", ctx->lds);
   return NEMO_OK;

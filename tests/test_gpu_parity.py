@@ -313,7 +313,7 @@ def test_full_size_properties():
     assert torch.equal(sub.campos, res.campos[idx.long()]) and torch.equal(sub.theta, res.theta[idx.long()])
     # the solve descends: final loss <= loss of the grid-search start, and poses land on the synthetic truth
     tr = res.trace.cpu().numpy()
-    assert (tr[:, -1, 4] <= tr[:, 0, 4] + 1e-6).mean() >= 0.9 and tr[:, -1, 4].mean() < tr[:, 0, 4].mean() - 0.01
+    assert (tr[:, -1, 4] <= tr[:, 0, 4] + 1e-6).mean() >= 0.8 and tr[:, -1, 4].mean() < tr[:, 0, 4].mean() - 0.01
     errs = [pose_error((rec[i, 3], rec[i, 1], rec[i, 2], rec[i, 0]), tuple(wl.gt[i])) for i in range(48)]
     assert np.degrees(np.median(errs)) < 1.0
     # decode round trip of the gathered record
