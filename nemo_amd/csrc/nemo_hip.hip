@@ -33,6 +33,10 @@ namespace {
 constexpr int NT = 1024;       // threads per workgroup of the pose kernels (one workgroup per CU)
 constexpr int NW = NT / 64;    // waves per workgroup
 constexpr int RED_N = 16;      // floats per wave in the reduction scratch
+#ifndef NEMO_CHUNK
+#define NEMO_CHUNK 128
+#endif
+constexpr int CH = NEMO_CHUNK;  // covered pixels per score chunk (multiple of 64)
 constexpr int UST_N = 96;      // floats of workgroup-uniform state kept in LDS
 // uniform-state slots: R[0..8] T[9..11] p[12..15] m[16..19] v[20..23] K[24], chunk counter [25], block totals [32..45],
 // camera intermediates of the current iterate [48..82] (kept for the camera backward)
@@ -71,6 +75,7 @@ struct KParams {
   int vmax;  // vertex capacity of the LDS arrays
   int fmax;  // face capacity of the LDS arrays
   unsigned w_magic;  // floor(2^32 / w) + 1: p / w == umulhi(p, w_magic) for p, w < 2^16
+  int zb_bytes;      // z-buffer region: max(8*cap, chunk partials + phase A->B hand-off buffer)
 };
 
 // ---------------------------------------------------------------- small math
@@ -326,12 +331,15 @@ struct Lds {
   uint32_t *list;        // [cap] covered pixels, face-major: (face id << 16) | window pixel index
   float *red;            // [NW][RED_N]
   float *ust;            // [UST_N] workgroup-uniform state (camera, Adam)
-  float *gbuf;           // [NW][64*3] dot products handed from phase A to phase B
 };
 
+__host__ __device__ inline size_t zb_region_bytes(int cap) {
+  const size_t a = (size_t)cap * 8, b = (size_t)(cap / CH + 2) * 64 + (size_t)NW * CH * 12;
+  return ((a > b ? a : b) + 15) & ~(size_t)15;
+}
 __host__ __device__ inline size_t lds_bytes(int cap, int vmax, int fmax, int wmax, int S) {
-  size_t b = (size_t)cap * 12 + (size_t)vmax * 32 + (size_t)fmax * 8;
-  b += (NW * RED_N + UST_N + NW * 64 * 3 + ((S + 3) & ~3)) * 4 + 64;
+  size_t b = zb_region_bytes(cap) + (size_t)cap * 4 + (size_t)vmax * 32 + (size_t)fmax * 8;
+  b += (NW * RED_N + UST_N + ((S + 3) & ~3)) * 4 + 64;
   (void)wmax;
   return (b + 15) & ~(size_t)15;
 }
@@ -339,14 +347,13 @@ __host__ __device__ inline size_t lds_bytes(int cap, int vmax, int fmax, int wma
 __device__ __forceinline__ Lds lds_carve(unsigned char *base, const KParams &P) {
   Lds L;
   L.zb = (u64 *)base;
-  L.sv = (f4 *)(base + (size_t)P.cap * 8);
+  L.sv = (f4 *)(base + (size_t)P.zb_bytes);
   L.xw = L.sv + P.vmax;
   L.fc = (us4 *)(L.xw + P.vmax);
   L.list = (uint32_t *)(L.fc + P.fmax);
   L.red = (float *)(L.list + P.cap);
   L.ust = L.red + NW * RED_N;
-  L.gbuf = L.ust + UST_N;
-  L.ndc = L.gbuf + NW * 64 * 3;
+  L.ndc = L.ust + UST_N;
   return L;
 }
 
@@ -574,10 +581,10 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
         constexpr int GPW = 64 / LPP;
         constexpr int NP = GRAD ? 13 : 1;  // partials per chunk: loss term, dL/dR (9), dL/dT (3)
         const int gl = lane & (LPP - 1), grp = lane / LPP;
-        float *gbuf = L.gbuf + wave * (64 * 3);
-        float *part = (float *)L.zb;       // [nchunks][16]
+        const int nchunks = (ntot + CH - 1) / CH;
+        float *part = (float *)L.zb;                                  // [nchunks][16]
+        float *gbuf = part + (size_t)(P.cap / CH + 2) * 16 + wave * (CH * 3);  // [NW][CH*3]
         int *ctr = (int *)(L.ust + U_CTR);
-        const int nchunks = (ntot + 63) >> 6;
         auto grab = [&]() {
           int v = 0;
           if (lane == 0) v = atomicAdd(ctr, 1);
@@ -585,8 +592,8 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
         };
         auto row_ptr = [&](int e) { return (gf4p)(gfeat + (size_t)(L.list[e] & 0xffffu) * D) + gl; };
         auto first_entry = [&](int c) {  // this lane group's first list entry in chunk c
-          const int cn_ = min(64, ntot - c * 64), per_ = (cn_ + GPW - 1) / GPW;
-          return c * 64 + min(grp * per_, cn_ - 1);
+          const int cn_ = min(CH, ntot - c * CH), per_ = (cn_ + GPW - 1) / GPW;
+          return c * CH + min(grp * per_, cn_ - 1);
         };
         int ccur = grab(), cnxt = grab();
         f4 xa[KIT], xb[KIT];  // ping-pong: current / next feature-row fragments
@@ -596,14 +603,19 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
           for (int k = 0; k < KIT; ++k) xa[k] = __builtin_nontemporal_load(Fp + LPP * k);
         }
         while (ccur < nchunks) {
-          const int cb = ccur * 64;
-          const int cn = min(64, ntot - cb);
+          const int cb = ccur * CH;
+          const int cn = min(CH, ntot - cb);
           const int per = (cn + GPW - 1) / GPW;  // entries per lane group in this chunk
           // first entry of this group in the wave's next chunk (or a harmless reload at the very end)
           const int e_next_chunk = cnxt < nchunks ? first_entry(cnxt) : cb + cn - 1;
-          // this lane's phase-B pixel: its clutter score is fetched now and lands during phase A
-          const uint32_t ent_b = L.list[cb + min(lane, cn - 1)];
-          const float cl = (P.clutter && clu) ? gclu[ent_b & 0xffffu] : 0.0f;
+          // this lane's phase-B pixels: their clutter scores are fetched now and land during phase A
+          uint32_t ent_bs[CH / 64];
+          float cls[CH / 64];
+#pragma unroll
+          for (int u = 0; u < CH / 64; ++u) {
+            ent_bs[u] = L.list[cb + min(u * 64 + lane, cn - 1)];
+            cls[u] = (P.clutter && clu) ? gclu[ent_bs[u] & 0xffffu] : 0.0f;
+          }
           // ---------------- phase A
           {
             int pf = -1, i0 = -1, i1 = -1, i2 = -1;
@@ -623,19 +635,19 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
                   i0 = n0;
                   const gf4p B = (gf4p)(bank + (size_t)i0 * D) + gl;
 #pragma unroll
-                  for (int k = 0; k < KIT; ++k) y0[k] = B[LPP * k];
+                  for (int k = 0; k < KIT; ++k) y0[k] = (NEMO_ABL & 2) ? f4{(float)i0, 1.f, 2.f, 3.f} : B[LPP * k];
                 }
                 if (n1 != i1) {
                   i1 = n1;
                   const gf4p B = (gf4p)(bank + (size_t)i1 * D) + gl;
 #pragma unroll
-                  for (int k = 0; k < KIT; ++k) y1[k] = B[LPP * k];
+                  for (int k = 0; k < KIT; ++k) y1[k] = (NEMO_ABL & 2) ? f4{(float)i1, 1.f, 2.f, 3.f} : B[LPP * k];
                 }
                 if (n2 != i2) {
                   i2 = n2;
                   const gf4p B = (gf4p)(bank + (size_t)i2 * D) + gl;
 #pragma unroll
-                  for (int k = 0; k < KIT; ++k) y2[k] = B[LPP * k];
+                  for (int k = 0; k < KIT; ++k) y2[k] = (NEMO_ABL & 2) ? f4{(float)i2, 1.f, 2.f, 3.f} : B[LPP * k];
                 }
               }
               // ... 2nd: the next entry's feature row, which stays in flight (vmcnt is in order)
@@ -643,7 +655,8 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
                 const int en = (j + 1 < per) ? cb + min(el + 1, cn - 1) : e_next_chunk;
                 const gf4p Fp = row_ptr(en);
 #pragma unroll
-                for (int k = 0; k < KIT; ++k) xnext[k] = __builtin_nontemporal_load(Fp + LPP * k);
+                for (int k = 0; k < KIT; ++k)
+                  xnext[k] = (NEMO_ABL & 1) ? f4{(float)en, 1.f, 2.f, 3.f} : __builtin_nontemporal_load(Fp + LPP * k);
               }
               f4 A0 = xc[0] * y0[0], A1 = xc[0] * y1[0], A2 = xc[0] * y2[0];
 #pragma unroll
@@ -659,7 +672,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
                 gbuf[3 * el] = g0; gbuf[3 * el + 1] = g1; gbuf[3 * el + 2] = g2;
               }
             };
-            int j = 0;
+            int j = (NEMO_ABL & 4) ? per : 0;
             for (; j + 1 < per; j += 2) {
               body(j, xa, xb);
               body(j + 1, xb, xa);
@@ -671,17 +684,22 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
             }
           }
           STAMP(8);
-          // ---------------- phase B: this lane's pixel -> its 13 contributions
+          // ---------------- phase B: this lane's pixels -> its 13 contributions
           float pl = 0.f;
           float GR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           float GT[3] = {0.f, 0.f, 0.f};
-          if (lane < cn) {
+#pragma unroll
+          for (int u = 0; u < CH / 64; ++u)
+          if (u * 64 + lane < cn) {
+            const uint32_t ent_b = ent_bs[u];
+            const float cl = cls[u];
+            const int lb = u * 64 + lane;
             const int p = (int)(ent_b & 0xffffu), f = (int)(ent_b >> 16);
             const int pi = (int)__umulhi((unsigned)p, P.w_magic), pj = p - pi * P.w;
             const int a = S - 1 - (pj + P.c0), b = S - 1 - (pi + P.r0);
             const us4 fv_ = L.fc[f];
             const int i0 = fv_.x, i1 = fv_.y, i2 = fv_.z;
-            const float g0 = gbuf[3 * lane], g1 = gbuf[3 * lane + 1], g2 = gbuf[3 * lane + 2];
+            const float g0 = gbuf[3 * lb], g1 = gbuf[3 * lb + 1], g2 = gbuf[3 * lb + 2];
             float v[9];
             load_face_verts(L, i0, i1, i2, v);
             const float px = L.ndc[a], py = L.ndc[b];
@@ -702,10 +720,10 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
             if (RAW) {
               ind = 1.0f;
             } else if (P.clutter) {
-              pl = fmaxf(obj, cl) - fmaxf(0.0f, cl);
+              pl += fmaxf(obj, cl) - fmaxf(0.0f, cl);
               ind = obj > cl ? 1.0f : (obj == cl ? 0.5f : 0.0f);
             } else {
-              pl = obj;
+              pl += obj;
               ind = 1.0f;
             }
             if (GRAD && ind != 0.0f) {
@@ -776,7 +794,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
         constexpr int NPB = GRAD ? 13 : 1;
         if (wave == 0 && lane < NPB) {
           const float *part = (const float *)L.zb;
-          const int nchunks = (ntot + 63) >> 6;
+          const int nchunks = (ntot + CH - 1) / CH;
           float t = L.ust[U_TOT + lane];
           for (int c = 0; c < nchunks; ++c) t += part[c * 16 + lane];
           L.ust[U_TOT + lane] = t;
@@ -1210,11 +1228,15 @@ static int plan_lds(nemo_ctx *ctx) {
   const int vmax = ctx->vmax_seen > 0 ? ((ctx->vmax_seen + 63) & ~63) : 64;
   const int fmax = ctx->fmax_seen > 0 ? ((ctx->fmax_seen + 63) & ~63) : 64;
   long avail = (long)LDS_BUDGET - (long)vmax * 32 - (long)fmax * 8 -
-               ((NW * RED_N + UST_N + NW * 64 * 3 + c.raster_size + 4) * 4 + 128);
+               ((NW * RED_N + UST_N + c.raster_size + 4) * 4 + 128);
   long cap = avail / (8 + 4);
   if (cap > (long)c.win_h * c.win_w) cap = (long)c.win_h * c.win_w;
   if ((long)c.win_h * c.win_w > 65536)
     return fail(ctx, NEMO_ERR_UNSUPPORTED, "window %dx%d has more than 65536 pixels (16-bit pixel ids)", c.win_h, c.win_w);
+  {  // the z-buffer region also hosts the chunk partials and the phase A->B hand-off buffer
+    const long fixed = (long)(NW * CH * 12 + 192);
+    if (avail - fixed < cap * 4 + 64 * (cap / CH)) cap = (avail - fixed) / 5;
+  }
   if (cap < c.win_w)
     return fail(ctx, NEMO_ERR_UNSUPPORTED,
                 "mesh with %d vertices / %d faces and window width %d do not fit the %d-byte LDS plan",
@@ -1222,6 +1244,7 @@ static int plan_lds(nemo_ctx *ctx) {
   ctx->P.cap = (int)cap;
   ctx->P.vmax = vmax;
   ctx->P.fmax = fmax;
+  ctx->P.zb_bytes = (int)zb_region_bytes((int)cap);
   ctx->P.w_magic = (unsigned)(0x100000000ULL / (unsigned long long)c.win_w) + 1u;
   ctx->lds = lds_bytes((int)cap, vmax, fmax, c.win_w, c.raster_size);
   if (ctx->lds > (size_t)LDS_BUDGET) return fail(ctx, NEMO_ERR_UNSUPPORTED, "LDS plan %zu > budget", ctx->lds);
