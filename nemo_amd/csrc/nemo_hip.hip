@@ -264,6 +264,26 @@ __device__ __forceinline__ float sum8(float v) {
   v += dpp_mov<0x141>(v);  // row_half_mirror
   return v;
 }
+// Sums of three values over each row of 16 lanes in nine DPP operations: the mirrored halves of a
+// row are duplicates after the first step, so they are merged and reduced together.  On return the
+// lanes of quad q (q = 0, 1, 2) of every row hold the row total of value q.
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ float dpp_merge(float keep, float take) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep), __builtin_bit_cast(int, take),
+                                                               CTRL, 0xF, BANK_MASK, false));
+}
+__device__ __forceinline__ float sum3_row16(float a, float b, float c) {
+  a += dpp_mov<0x140>(a);  // row_mirror
+  b += dpp_mov<0x140>(b);
+  c += dpp_mov<0x140>(c);
+  float z = dpp_merge<0xE4, 0xC>(a, c);  // lanes 8-15 carry c
+  z += dpp_mov<0x141>(z);                // row_half_mirror
+  b += dpp_mov<0x141>(b);
+  float w = dpp_merge<0xE4, 0xA>(z, b);  // quads 1 and 3 carry b
+  w += dpp_mov<0x4E>(w);
+  w += dpp_mov<0xB1>(w);
+  return w;
+}
 template <int LPP>
 __device__ __forceinline__ float sum_group(float v) {
   v = sum8(v);
@@ -303,7 +323,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // cycles it spent per phase (barrier waits included) into g_stamps; the shipped
 // library contains none of this.
 #ifndef NEMO_ABL
-#define NEMO_ABL 0  // diagnostic builds: 1 = no feature-row loads, 2 = no bank-row loads, 3 = neither, 4 = no phase A
+#define NEMO_ABL 0  // diagnostic builds (solve kernel only): 1 = no feature-row loads, 2 = no bank-row loads, 4 = no phase A loop
 #endif
 #ifdef NEMO_STAMPS
 __device__ unsigned long long g_stamps[16];
@@ -333,8 +353,37 @@ struct Lds {
   float *ust;            // [UST_N] workgroup-uniform state (camera, Adam)
 };
 
+// Score chunks come in guided sizes: CH entries for the bulk of the face-major list, then 64, then
+// 32 for the last NW*32 entries, so that the waves run out of work within a few pixels of each other.
+// The plan is a function of the list length only (the chunk-order sum stays deterministic).
+struct ChunkPlan {
+  int n_big, n_mid, b_mid, b_small, nchunks;
+};
+__host__ __device__ inline int max_chunks(int cap) { return cap / CH + 2 * NW + 8; }
+__device__ __forceinline__ ChunkPlan plan_chunks(int ntot) {
+  ChunkPlan c;
+  const int bulk = max(0, ntot - NW * (32 + 64));
+  c.n_big = (bulk + CH - 1) / CH;
+  c.b_mid = c.n_big * CH;  // < ntot - NW*96 + CH
+  const int mid = max(0, ntot - c.b_mid - NW * 32);
+  c.n_mid = (mid + 63) / 64;
+  c.b_small = c.b_mid + c.n_mid * 64;
+  c.nchunks = c.n_big + c.n_mid + (max(0, ntot - c.b_small) + 31) / 32;
+  return c;
+}
+__device__ __forceinline__ void chunk_range(const ChunkPlan &c, int ntot, int id, int &cb, int &cn) {
+  if (id < c.n_big) {
+    cb = id * CH; cn = CH;
+  } else if (id < c.n_big + c.n_mid) {
+    cb = c.b_mid + (id - c.n_big) * 64; cn = 64;
+  } else {
+    cb = c.b_small + (id - c.n_big - c.n_mid) * 32; cn = 32;
+  }
+  cn = min(cn, ntot - cb);
+}
+
 __host__ __device__ inline size_t zb_region_bytes(int cap) {
-  const size_t a = (size_t)cap * 8, b = (size_t)(cap / CH + 2) * 64 + (size_t)NW * CH * 12;
+  const size_t a = (size_t)cap * 8, b = (size_t)max_chunks(cap) * 64 + (size_t)NW * CH * (12 + 16);
   return ((a > b ? a : b) + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t lds_bytes(int cap, int vmax, int fmax, int wmax, int S) {
@@ -382,7 +431,10 @@ __device__ __forceinline__ float block_total(const Lds &L, int i) { return L.ust
 template <int D, bool PERSP, bool GRAD, bool SCORE, bool RAW = false>
 __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, const float *__restrict__ feat,
                           const float *__restrict__ clu, EmitOut emit) {
-  constexpr int KIT = 4;                    // 16-byte loads per row per lane
+#ifndef NEMO_KIT
+#define NEMO_KIT 2
+#endif
+  constexpr int KIT = NEMO_KIT;             // 16-byte loads per row per lane
   constexpr int LPP = D / (4 * KIT);        // lanes per pixel: 8 (D=128) or 16 (D=256)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int S = P.S;
@@ -581,82 +633,95 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
         constexpr int GPW = 64 / LPP;
         constexpr int NP = GRAD ? 13 : 1;  // partials per chunk: loss term, dL/dR (9), dL/dT (3)
         const int gl = lane & (LPP - 1), grp = lane / LPP;
-        const int nchunks = (ntot + CH - 1) / CH;
+        const ChunkPlan cp = plan_chunks(ntot);
+        const int nchunks = cp.nchunks;
         float *part = (float *)L.zb;                                  // [nchunks][16]
-        float *gbuf = part + (size_t)(P.cap / CH + 2) * 16 + wave * (CH * 3);  // [NW][CH*3]
+        uint4 *rec = (uint4 *)(part + (size_t)max_chunks(P.cap) * 16) + wave * CH;               // [NW][CH]
+        float *gbuf = (float *)((uint4 *)(part + (size_t)max_chunks(P.cap) * 16) + NW * CH) + wave * (CH * 3);  // [NW][CH*3]
         int *ctr = (int *)(L.ust + U_CTR);
         auto grab = [&]() {
           int v = 0;
           if (lane == 0) v = atomicAdd(ctr, 1);
           return __builtin_amdgcn_readfirstlane(v);
         };
-        auto row_ptr = [&](int e) { return (gf4p)(gfeat + (size_t)(L.list[e] & 0xffffu) * D) + gl; };
-        auto first_entry = [&](int c) {  // this lane group's first list entry in chunk c
-          const int cn_ = min(CH, ntot - c * CH), per_ = (cn_ + GPW - 1) / GPW;
-          return c * CH + min(grp * per_, cn_ - 1);
+        // rows are addressed as uniform base + 32-bit byte offset (feature window and bank are < 4 GiB)
+        typedef const __attribute__((address_space(1))) char *gbytep;
+        const gbytep fbytes = (gbytep)gfeat, bbytes = (gbytep)bank;
+        const uint32_t gl16 = (uint32_t)gl * 16u;
+        auto first_off = [&](int c) {  // byte offset of the feature row of this lane group's first entry in chunk c
+          int cb_, cn_;
+          chunk_range(cp, ntot, c, cb_, cn_);
+          const int per_ = (cn_ + GPW - 1) / GPW;
+          return (L.list[cb_ + min(grp * per_, cn_ - 1)] & 0xffffu) * (uint32_t)(D * 4) + gl16;
         };
         int ccur = grab(), cnxt = grab();
         f4 xa[KIT], xb[KIT];  // ping-pong: current / next feature-row fragments
         if (ccur < nchunks) {
-          const gf4p Fp = row_ptr(first_entry(ccur));
+          const gf4p Fp = (gf4p)(fbytes + first_off(ccur));
 #pragma unroll
           for (int k = 0; k < KIT; ++k) xa[k] = __builtin_nontemporal_load(Fp + LPP * k);
         }
         while (ccur < nchunks) {
-          const int cb = ccur * CH;
-          const int cn = min(CH, ntot - cb);
+          int cb, cn;
+          chunk_range(cp, ntot, ccur, cb, cn);
           const int per = (cn + GPW - 1) / GPW;  // entries per lane group in this chunk
-          // first entry of this group in the wave's next chunk (or a harmless reload at the very end)
-          const int e_next_chunk = cnxt < nchunks ? first_entry(cnxt) : cb + cn - 1;
-          // this lane's phase-B pixels: their clutter scores are fetched now and land during phase A
+          // ---------------- records (one lane per entry): everything phase A needs to know about an entry
+          // -- feature-row byte offset and the three bank rows -- is worked out once here, 64 entries per
+          // instruction, instead of by every lane of a group inside the loop.  The same pass fetches this
+          // lane's phase-B list entries and clutter scores (they land during phase A).
           uint32_t ent_bs[CH / 64];
           float cls[CH / 64];
 #pragma unroll
           for (int u = 0; u < CH / 64; ++u) {
-            ent_bs[u] = L.list[cb + min(u * 64 + lane, cn - 1)];
-            cls[u] = (P.clutter && clu) ? gclu[ent_bs[u] & 0xffffu] : 0.0f;
+            const uint32_t ent = L.list[cb + min(u * 64 + lane, cn - 1)];
+            ent_bs[u] = ent;
+            cls[u] = (P.clutter && clu) ? gclu[ent & 0xffffu] : 0.0f;
+            if (u * 64 < cn) {
+              const us4 fv_ = L.fc[ent >> 16];
+              rec[u * 64 + lane] = uint4{(ent & 0xffffu) * (uint32_t)(D * 4), (uint32_t)fv_.x | ((uint32_t)fv_.y << 16),
+                                         (uint32_t)fv_.z, 0u};
+            }
           }
           // ---------------- phase A
           {
-            int pf = -1, i0 = -1, i1 = -1, i2 = -1;
+            // first feature row of this group in the wave's next chunk (or a harmless reload at the very end)
+            const int e0 = grp * per;
+            uint4 R0 = rec[min(e0, cn - 1)], R1 = rec[min(e0 + 1, cn - 1)];  // records run two entries ahead
+            const uint32_t off_next_chunk = cnxt < nchunks ? first_off(cnxt) : R0.x + gl16;
+            int i0 = -1, i1 = -1, i2 = -1;
             f4 y0[KIT], y1[KIT], y2[KIT];
 #pragma unroll
             for (int k = 0; k < KIT; ++k) y0[k] = y1[k] = y2[k] = f4{0.f, 0.f, 0.f, 0.f};
             auto body = [&](int j, f4(&xc)[KIT], f4(&xnext)[KIT]) {
-              const int el = grp * per + j;
-              const int e = cb + min(el, cn - 1);
-              const int f = (int)(L.list[e] >> 16);
+              const int el = e0 + j;
+              const uint4 R2 = rec[min(el + 2, cn - 1)];
               // 1st: the loads this entry depends on (bank rows of a changed vertex slot) ...
-              if (f != pf) {
-                pf = f;
-                const us4 fv_ = L.fc[f];
-                const int n0 = fv_.x, n1 = fv_.y, n2 = fv_.z;
-                if (n0 != i0) {
-                  i0 = n0;
-                  const gf4p B = (gf4p)(bank + (size_t)i0 * D) + gl;
+              const int n0 = (int)(R0.y & 0xffffu), n1 = (int)(R0.y >> 16), n2 = (int)R0.z;
+              if (n0 != i0) {
+                i0 = n0;
+                const gf4p B = (gf4p)(bbytes + ((uint32_t)n0 * (uint32_t)(D * 4) + gl16));
 #pragma unroll
-                  for (int k = 0; k < KIT; ++k) y0[k] = (NEMO_ABL & 2) ? f4{(float)i0, 1.f, 2.f, 3.f} : B[LPP * k];
-                }
-                if (n1 != i1) {
-                  i1 = n1;
-                  const gf4p B = (gf4p)(bank + (size_t)i1 * D) + gl;
+                for (int k = 0; k < KIT; ++k) y0[k] = (GRAD && (NEMO_ABL & 2)) ? f4{(float)n0, 1.f, 2.f, 3.f} : B[LPP * k];
+              }
+              if (n1 != i1) {
+                i1 = n1;
+                const gf4p B = (gf4p)(bbytes + ((uint32_t)n1 * (uint32_t)(D * 4) + gl16));
 #pragma unroll
-                  for (int k = 0; k < KIT; ++k) y1[k] = (NEMO_ABL & 2) ? f4{(float)i1, 1.f, 2.f, 3.f} : B[LPP * k];
-                }
-                if (n2 != i2) {
-                  i2 = n2;
-                  const gf4p B = (gf4p)(bank + (size_t)i2 * D) + gl;
+                for (int k = 0; k < KIT; ++k) y1[k] = (GRAD && (NEMO_ABL & 2)) ? f4{(float)n1, 1.f, 2.f, 3.f} : B[LPP * k];
+              }
+              if (n2 != i2) {
+                i2 = n2;
+                const gf4p B = (gf4p)(bbytes + ((uint32_t)n2 * (uint32_t)(D * 4) + gl16));
 #pragma unroll
-                  for (int k = 0; k < KIT; ++k) y2[k] = (NEMO_ABL & 2) ? f4{(float)i2, 1.f, 2.f, 3.f} : B[LPP * k];
-                }
+                for (int k = 0; k < KIT; ++k) y2[k] = (GRAD && (NEMO_ABL & 2)) ? f4{(float)n2, 1.f, 2.f, 3.f} : B[LPP * k];
               }
               // ... 2nd: the next entry's feature row, which stays in flight (vmcnt is in order)
               {
-                const int en = (j + 1 < per) ? cb + min(el + 1, cn - 1) : e_next_chunk;
-                const gf4p Fp = row_ptr(en);
+                const uint32_t offn = (j + 1 < per) ? R1.x + gl16 : off_next_chunk;
+                const gf4p Fp = (gf4p)(fbytes + offn);
 #pragma unroll
                 for (int k = 0; k < KIT; ++k)
-                  xnext[k] = (NEMO_ABL & 1) ? f4{(float)en, 1.f, 2.f, 3.f} : __builtin_nontemporal_load(Fp + LPP * k);
+                  xnext[k] = (GRAD && (NEMO_ABL & 1)) ? f4{(float)offn, 1.f, 2.f, 3.f} : __builtin_nontemporal_load(Fp + LPP * k);
               }
               f4 A0 = xc[0] * y0[0], A1 = xc[0] * y1[0], A2 = xc[0] * y2[0];
 #pragma unroll
@@ -665,14 +730,23 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
                 A1 = __builtin_elementwise_fma(xc[k], y1[k], A1);
                 A2 = __builtin_elementwise_fma(xc[k], y2[k], A2);
               }
-              const float g0 = sum_group<LPP>((A0.x + A0.y) + (A0.z + A0.w));
-              const float g1 = sum_group<LPP>((A1.x + A1.y) + (A1.z + A1.w));
-              const float g2 = sum_group<LPP>((A2.x + A2.y) + (A2.z + A2.w));
-              if (gl == 0 && el < cn) {
-                gbuf[3 * el] = g0; gbuf[3 * el + 1] = g1; gbuf[3 * el + 2] = g2;
+              float s0 = (A0.x + A0.y) + (A0.z + A0.w), s1 = (A1.x + A1.y) + (A1.z + A1.w),
+                    s2 = (A2.x + A2.y) + (A2.z + A2.w);
+              if (LPP >= 16) {
+                if (LPP >= 32) {
+                  s0 += __shfl_xor(s0, 16); s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+                }
+                const float w = sum3_row16(s0, s1, s2);  // quad q of the row holds the total of value q (q < 3)
+                if (el < cn && (gl & 3) == 0 && gl < 12) gbuf[3 * el + (gl >> 2)] = w;
+              } else {
+                const float g0 = sum8(s0), g1 = sum8(s1), g2 = sum8(s2);
+                if (gl == 0 && el < cn) {
+                  gbuf[3 * el] = g0; gbuf[3 * el + 1] = g1; gbuf[3 * el + 2] = g2;
+                }
               }
+              R0 = R1; R1 = R2;
             };
-            int j = (NEMO_ABL & 4) ? per : 0;
+            int j = (GRAD && (NEMO_ABL & 4)) ? per : 0;
             for (; j + 1 < per; j += 2) {
               body(j, xa, xb);
               body(j + 1, xb, xa);
@@ -794,7 +868,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
         constexpr int NPB = GRAD ? 13 : 1;
         if (wave == 0 && lane < NPB) {
           const float *part = (const float *)L.zb;
-          const int nchunks = (ntot + CH - 1) / CH;
+          const int nchunks = plan_chunks(ntot).nchunks;
           float t = L.ust[U_TOT + lane];
           for (int c = 0; c < nchunks; ++c) t += part[c * 16 + lane];
           L.ust[U_TOT + lane] = t;
@@ -1234,7 +1308,7 @@ static int plan_lds(nemo_ctx *ctx) {
   if ((long)c.win_h * c.win_w > 65536)
     return fail(ctx, NEMO_ERR_UNSUPPORTED, "window %dx%d has more than 65536 pixels (16-bit pixel ids)", c.win_h, c.win_w);
   {  // the z-buffer region also hosts the chunk partials and the phase A->B hand-off buffer
-    const long fixed = (long)(NW * CH * 12 + 192);
+    const long fixed = (long)(NW * CH * (12 + 16) + 64 * (2 * NW + 8) + 192);
     if (avail - fixed < cap * 4 + 64 * (cap / CH)) cap = (avail - fixed) / 5;
   }
   if (cap < c.win_w)

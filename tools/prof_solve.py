@@ -17,8 +17,9 @@ ap.add_argument('--images', type=int, default=512)
 ap.add_argument('--steps', type=int, default=60)
 ap.add_argument('--reps', type=int, default=2)
 ap.add_argument('--grid', action='store_true', help='also time the grid search')
+ap.add_argument('--lr0', action='store_true', help='zero learning rate: every step re-evaluates the initial pose (fixed work for ablations)')
 args = ap.parse_args()
-wl = twelve_class_workload(args.images, seed=1000, cfg=SolverConfig(total_epochs=args.steps))
+wl = twelve_class_workload(args.images, seed=1000, cfg=SolverConfig(total_epochs=args.steps, **({'lr': 0.0} if args.lr0 else {})))
 s, eng = wl.solver, wl.solver.engine
 clu = eng.clutter_score(wl.feats, wl.clutter)
 C0, th0, _, _ = eng.grid_search(wl.feats, clu, s.grid_C, s.grid_theta, mesh_idx=wl.mesh_idx, grid_idx=wl.mesh_idx)
