@@ -125,6 +125,17 @@ int nemo_grid_search(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const i
                      const float *d_grid_C, const float *d_grid_theta, int32_t G, float *d_losses,
                      float *d_C0, float *d_theta0, int32_t *d_best, void *stream);
 
+/* get_pre_render_samples (code/MeshPoseSolveAll.py:62-82): the reference renders every grid pose once
+ * per category and compares each image against the stored renders.  Here the image-independent part
+ * of a grid pose -- which pixels a mesh covers and with which face -- is rendered once per listed
+ * (mesh, grid) pair and kept by the context; nemo_grid_search then skips projection-independent work
+ * for jobs whose pair is stored (others are rendered on the fly; results are the same either way).
+ * The store is tied to the two device pointers and G and is dropped by n_pairs == 0 or the next call.
+ * h_pair_mesh / h_pair_grid are HOST arrays.  Setup call: allocates n_pairs*G*win_h*win_w*4 bytes. */
+int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_grid_theta, int32_t n_grids,
+                        int32_t G, const int32_t *h_pair_mesh, const int32_t *h_pair_grid, int32_t n_pairs,
+                        void *stream);
+
 /* The 300-step solve (code/MeshPoseSolveAll.py:227-250): render, score, loss,
  * backward and Adam on (Cx,Cy,Cz,theta) fused in one persistent launch, one
  * workgroup per job; schedule from nemo_set_schedule.  d_pose f32[N][4]

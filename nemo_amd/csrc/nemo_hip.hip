@@ -19,6 +19,7 @@
 // explicit fmaf.  Reference citations (file:line) are into Angtian/NeMo.
 
 #include <hip/hip_runtime.h>
+#include <vector>
 #include <math.h>
 #include <stdarg.h>
 #include <stdint.h>
@@ -30,7 +31,10 @@
 
 namespace {
 
-constexpr int NT = 1024;       // threads per workgroup of the pose kernels (one workgroup per CU)
+#ifndef NEMO_NT
+#define NEMO_NT 1024
+#endif
+constexpr int NT = NEMO_NT;    // threads per workgroup of the pose kernels
 constexpr int NW = NT / 64;    // waves per workgroup
 constexpr int RED_N = 16;      // floats per wave in the reduction scratch
 #ifndef NEMO_CHUNK
@@ -44,7 +48,7 @@ constexpr int U_R = 0, U_T = 9, U_P = 12, U_M = 16, U_V = 20, U_K = 24, U_CTR = 
 // block totals: [0] loss term, [1..9] dL/dR, [10..12] dL/dT, [13] covered pixels
 constexpr int T_LOSS = 0, T_GR = 1, T_GT = 10, T_NCOV = 13;
 constexpr int MAX_MESHES = 1024;
-constexpr int LDS_BUDGET = 160 * 1024;  // one workgroup per CU owns the whole LDS
+constexpr int LDS_BUDGET = 160 * 1024 / (1024 / NT);  // the workgroups resident on a CU share its 160 KiB
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
@@ -345,7 +349,6 @@ __device__ unsigned long long g_stamps[16];
 struct Lds {
   u64 *zb;               // [cap] packed z-buffer
   f4 *sv;                // [vmax] screen verts (u, t, z_view, -)
-  f4 *xw;                // [vmax] world verts (x, y, z, -)
   us4 *fc;               // [fmax] face vertex ids (i0, i1, i2, -) as 16-bit
   float *ndc;            // [S] pixel-centre NDC coordinate of flipped index a: PixToNdc(a, S)
   uint32_t *list;        // [cap] covered pixels, face-major: (face id << 16) | window pixel index
@@ -387,7 +390,7 @@ __host__ __device__ inline size_t zb_region_bytes(int cap) {
   return ((a > b ? a : b) + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t lds_bytes(int cap, int vmax, int fmax, int wmax, int S) {
-  size_t b = zb_region_bytes(cap) + (size_t)cap * 4 + (size_t)vmax * 32 + (size_t)fmax * 8;
+  size_t b = zb_region_bytes(cap) + (size_t)cap * 4 + (size_t)vmax * 16 + (size_t)fmax * 8;
   b += (NW * RED_N + UST_N + ((S + 3) & ~3)) * 4 + 64;
   (void)wmax;
   return (b + 15) & ~(size_t)15;
@@ -397,8 +400,7 @@ __device__ __forceinline__ Lds lds_carve(unsigned char *base, const KParams &P) 
   Lds L;
   L.zb = (u64 *)base;
   L.sv = (f4 *)(base + (size_t)P.zb_bytes);
-  L.xw = L.sv + P.vmax;
-  L.fc = (us4 *)(L.xw + P.vmax);
+  L.fc = (us4 *)(L.sv + P.vmax);
   L.list = (uint32_t *)(L.fc + P.fmax);
   L.red = (float *)(L.list + P.cap);
   L.ust = L.red + NW * RED_N;
@@ -406,10 +408,22 @@ __device__ __forceinline__ Lds lds_carve(unsigned char *base, const KParams &P) 
   return L;
 }
 
+constexpr int MAX_GRIDS = 64;
+constexpr int GRID_POSES_PER_WG = 4;
+struct PreStore {  // pre-rendered grid poses (device pointers; slot == nullptr: none)
+  const int32_t *slot;   // [MAX_MESHES][MAX_GRIDS] -> pair slot or -1
+  const int32_t *cnt;    // [pairs][G] list lengths
+  const uint32_t *list;  // [pairs][G][stride] face-major lists
+  size_t stride;
+};
+
 struct EmitOut {  // standalone rasterizer outputs (window), may be null
   int32_t *p2f;
   float *bary;
   float *zbuf;
+  uint32_t *list_out;        // pre-render: the face-major list itself
+  const uint32_t *pre_list;  // PRE: list built earlier by prerender_kernel
+  int pre_cnt;
 };
 
 __device__ __forceinline__ void load_face_verts(const Lds &L, int i0, int i1, int i2, float *v) {
@@ -428,7 +442,7 @@ __device__ __forceinline__ float block_total(const Lds &L, int i) { return L.ust
 // RAW = true: `feat` holds an upstream gradient dL/d(out) [h][w][D] of the
 // interpolated map and the routine back-propagates it (module path); otherwise
 // `feat` is the image feature map and the loss of MeshPoseSolveAll.py:58-59 is used.
-template <int D, bool PERSP, bool GRAD, bool SCORE, bool RAW = false>
+template <int D, bool PERSP, bool GRAD, bool SCORE, bool RAW = false, bool PRE = false>
 __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, const float *__restrict__ feat,
                           const float *__restrict__ clu, EmitOut emit) {
 #ifndef NEMO_KIT
@@ -442,6 +456,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
   const int V = M.V, F = M.F;
   const float s = P.s;
   const gf32p bank = as_global(M.bank);
+  const gf32p gverts = as_global(M.verts);
   const gf32p gfeat = as_global(feat);
   const gf32p gclu = as_global(clu);
 
@@ -456,8 +471,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
     const float m01 = R[1] * s, m11 = R[4] * s, m21 = R[7] * s, m31 = T[1] * s;
     const float r02 = R[2], r12 = R[5], r22 = R[8], t2 = T[2];
     for (int v = tid; v < V; v += NT) {
-      const f4 Xv = L.xw[v];
-      const float x = Xv.x, y = Xv.y, z = Xv.z;
+      const float x = gverts[3 * v], y = gverts[3 * v + 1], z = gverts[3 * v + 2];
       const float xc = ((x * m00 + y * m10) + z * m20) + m30;
       const float yc = ((x * m01 + y * m11) + z * m21) + m31;
       const float zv = ((x * r02 + y * r12) + z * r22) + t2;
@@ -509,9 +523,314 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
   const bool empty_box = (bw <= 0) || (b_hi < b_lo);
   STAMP(0);
 
-  int ncov = 0;
+  int ncov = 0, ebase = 0;
 
-  if (!empty_box) {
+  // ---- consumer of one band's face-major list (L.list[0..ntot)): emit or score; ends behind a barrier
+  auto consume = [&](const int ntot, const int ebase) {
+    if (!SCORE) {
+      // pre-render: keep the list itself; standalone rasterizer: emit pix_to_face / bary / zbuf
+      if (emit.list_out)
+        for (int e = tid; e < ntot; e += NT) emit.list_out[ebase + e] = L.list[e];
+      for (int e = tid; emit.p2f && e < ntot; e += NT) {
+        const uint32_t ent = L.list[e];
+        const int p = (int)(ent & 0xffffu), f = (int)(ent >> 16);
+        const int i = (int)__umulhi((unsigned)p, P.w_magic), j = p - i * P.w;
+        const int a = S - 1 - (j + P.c0), b = S - 1 - (i + P.r0);
+        const us4 fv_ = L.fc[f];
+        float v[9];
+        load_face_verts(L, fv_.x, fv_.y, fv_.z, v);
+        Frag fr;
+        fr.b0 = fr.b1 = fr.b2 = fr.pz = -1.0f;
+        frag_eval<PERSP>(L.ndc[a], L.ndc[b], v, face_area_eps(v, P.keps), fr);
+        emit.p2f[p] = f;
+        emit.bary[3 * p] = fr.b0; emit.bary[3 * p + 1] = fr.b1; emit.bary[3 * p + 2] = fr.b2;
+        if (emit.zbuf) emit.zbuf[p] = fr.pz;
+      }
+    } else {
+      // ---- 3. fused interpolate + score (+ backward).  Each wave owns a contiguous
+      // segment of the face-major list and works through it in chunks of 64 pixels:
+      //  phase A (LPP lanes per pixel): 16-byte loads of the pixel's feature row and of
+      //    the face's three vertex-bank rows, three D-long dot products reduced with
+      //    DPP, results parked in a wave-private LDS buffer.  A lane group walks
+      //    consecutive list entries and re-reads a bank row only when that vertex slot
+      //    changes (the two triangles of a cuboid cell share two of their three slots).
+      //    The next entry's feature row is always in flight (ping-pong registers); the
+      //    prefetch is unconditional because a conditional load would make the compiler
+      //    drain vmcnt to zero every iteration.
+      //  phase B (one lane per pixel): barycentrics, object score, loss term and the
+      //    hand-derived backward to dL/dR, dL/dT accumulators.
+      // Both phases are wave-local (LDS operations of one wave complete in order), so
+      // there is no workgroup barrier inside this loop.
+      // Chunks are handed out dynamically (LDS counter) so that no wave idles at the band barrier;
+      // every chunk leaves its 14 partial sums in LDS (the z-buffer is dead by now and hosts them)
+      // and they are added up in chunk order afterwards, so the totals do not depend on which
+      // wave ran which chunk.
+      constexpr int GPW = 64 / LPP;
+      constexpr int NP = GRAD ? 13 : 1;  // partials per chunk: loss term, dL/dR (9), dL/dT (3)
+      const int gl = lane & (LPP - 1), grp = lane / LPP;
+      const ChunkPlan cp = plan_chunks(ntot);
+      const int nchunks = cp.nchunks;
+      float *part = (float *)L.zb;                                  // [nchunks][16]
+      uint4 *rec = (uint4 *)(part + (size_t)max_chunks(P.cap) * 16) + wave * CH;               // [NW][CH]
+      float *gbuf = (float *)((uint4 *)(part + (size_t)max_chunks(P.cap) * 16) + NW * CH) + wave * (CH * 3);  // [NW][CH*3]
+      int *ctr = (int *)(L.ust + U_CTR);
+      auto grab = [&]() {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(ctr, 1);
+        return __builtin_amdgcn_readfirstlane(v);
+      };
+      // rows are addressed as uniform base + 32-bit byte offset (feature window and bank are < 4 GiB)
+      typedef const __attribute__((address_space(1))) char *gbytep;
+      const gbytep fbytes = (gbytep)gfeat, bbytes = (gbytep)bank;
+      const uint32_t gl16 = (uint32_t)gl * 16u;
+      auto first_off = [&](int c) {  // byte offset of the feature row of this lane group's first entry in chunk c
+        int cb_, cn_;
+        chunk_range(cp, ntot, c, cb_, cn_);
+        const int per_ = (cn_ + GPW - 1) / GPW;
+        return (L.list[cb_ + min(grp * per_, cn_ - 1)] & 0xffffu) * (uint32_t)(D * 4) + gl16;
+      };
+      int ccur = grab(), cnxt = grab();
+      f4 xa[KIT], xb[KIT];  // ping-pong: current / next feature-row fragments
+      if (ccur < nchunks) {
+        const gf4p Fp = (gf4p)(fbytes + first_off(ccur));
+#pragma unroll
+        for (int k = 0; k < KIT; ++k) xa[k] = __builtin_nontemporal_load(Fp + LPP * k);
+      }
+      while (ccur < nchunks) {
+        int cb, cn;
+        chunk_range(cp, ntot, ccur, cb, cn);
+        const int per = (cn + GPW - 1) / GPW;  // entries per lane group in this chunk
+        // ---------------- records (one lane per entry): everything phase A needs to know about an entry
+        // -- feature-row byte offset and the three bank rows -- is worked out once here, 64 entries per
+        // instruction, instead of by every lane of a group inside the loop.  The same pass fetches this
+        // lane's phase-B list entries and clutter scores (they land during phase A).
+        uint32_t ent_bs[CH / 64];
+        float cls[CH / 64];
+#pragma unroll
+        for (int u = 0; u < CH / 64; ++u) {
+          const uint32_t ent = L.list[cb + min(u * 64 + lane, cn - 1)];
+          ent_bs[u] = ent;
+          cls[u] = (P.clutter && clu) ? gclu[ent & 0xffffu] : 0.0f;
+          if (u * 64 < cn) {
+            const us4 fv_ = L.fc[ent >> 16];
+            rec[u * 64 + lane] = uint4{(ent & 0xffffu) * (uint32_t)(D * 4), (uint32_t)fv_.x | ((uint32_t)fv_.y << 16),
+                                       (uint32_t)fv_.z, 0u};
+          }
+        }
+        // ---------------- phase A
+        {
+          // first feature row of this group in the wave's next chunk (or a harmless reload at the very end)
+          const int e0 = grp * per;
+          uint4 R0 = rec[min(e0, cn - 1)], R1 = rec[min(e0 + 1, cn - 1)];  // records run two entries ahead
+          const uint32_t off_next_chunk = cnxt < nchunks ? first_off(cnxt) : R0.x + gl16;
+          int i0 = -1, i1 = -1, i2 = -1;
+          f4 y0[KIT], y1[KIT], y2[KIT];
+#pragma unroll
+          for (int k = 0; k < KIT; ++k) y0[k] = y1[k] = y2[k] = f4{0.f, 0.f, 0.f, 0.f};
+          auto body = [&](int j, f4(&xc)[KIT], f4(&xnext)[KIT]) {
+            const int el = e0 + j;
+            const uint4 R2 = rec[min(el + 2, cn - 1)];
+            // 1st: the loads this entry depends on (bank rows of a changed vertex slot) ...
+            const int n0 = (int)(R0.y & 0xffffu), n1 = (int)(R0.y >> 16), n2 = (int)R0.z;
+            if (n0 != i0) {
+              i0 = n0;
+              const gf4p B = (gf4p)(bbytes + ((uint32_t)n0 * (uint32_t)(D * 4) + gl16));
+#pragma unroll
+              for (int k = 0; k < KIT; ++k) y0[k] = (GRAD && (NEMO_ABL & 2)) ? f4{(float)n0, 1.f, 2.f, 3.f} : B[LPP * k];
+            }
+            if (n1 != i1) {
+              i1 = n1;
+              const gf4p B = (gf4p)(bbytes + ((uint32_t)n1 * (uint32_t)(D * 4) + gl16));
+#pragma unroll
+              for (int k = 0; k < KIT; ++k) y1[k] = (GRAD && (NEMO_ABL & 2)) ? f4{(float)n1, 1.f, 2.f, 3.f} : B[LPP * k];
+            }
+            if (n2 != i2) {
+              i2 = n2;
+              const gf4p B = (gf4p)(bbytes + ((uint32_t)n2 * (uint32_t)(D * 4) + gl16));
+#pragma unroll
+              for (int k = 0; k < KIT; ++k) y2[k] = (GRAD && (NEMO_ABL & 2)) ? f4{(float)n2, 1.f, 2.f, 3.f} : B[LPP * k];
+            }
+            // ... 2nd: the next entry's feature row, which stays in flight (vmcnt is in order)
+            {
+              const uint32_t offn = (j + 1 < per) ? R1.x + gl16 : off_next_chunk;
+              const gf4p Fp = (gf4p)(fbytes + offn);
+#pragma unroll
+              for (int k = 0; k < KIT; ++k)
+                xnext[k] = (GRAD && (NEMO_ABL & 1)) ? f4{(float)offn, 1.f, 2.f, 3.f} : __builtin_nontemporal_load(Fp + LPP * k);
+            }
+            f4 A0 = xc[0] * y0[0], A1 = xc[0] * y1[0], A2 = xc[0] * y2[0];
+#pragma unroll
+            for (int k = 1; k < KIT; ++k) {
+              A0 = __builtin_elementwise_fma(xc[k], y0[k], A0);
+              A1 = __builtin_elementwise_fma(xc[k], y1[k], A1);
+              A2 = __builtin_elementwise_fma(xc[k], y2[k], A2);
+            }
+            float s0 = (A0.x + A0.y) + (A0.z + A0.w), s1 = (A1.x + A1.y) + (A1.z + A1.w),
+                  s2 = (A2.x + A2.y) + (A2.z + A2.w);
+            if (LPP >= 16) {
+              if (LPP >= 32) {
+                s0 += __shfl_xor(s0, 16); s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+              }
+              const float w = sum3_row16(s0, s1, s2);  // quad q of the row holds the total of value q (q < 3)
+              if (el < cn && (gl & 3) == 0 && gl < 12) gbuf[3 * el + (gl >> 2)] = w;
+            } else {
+              const float g0 = sum8(s0), g1 = sum8(s1), g2 = sum8(s2);
+              if (gl == 0 && el < cn) {
+                gbuf[3 * el] = g0; gbuf[3 * el + 1] = g1; gbuf[3 * el + 2] = g2;
+              }
+            }
+            R0 = R1; R1 = R2;
+          };
+          int j = (GRAD && (NEMO_ABL & 4)) ? per : 0;
+          for (; j + 1 < per; j += 2) {
+            body(j, xa, xb);
+            body(j + 1, xb, xa);
+          }
+          if (j < per) {  // odd tail: one more entry, then put the prefetched row back in xa
+            body(j, xa, xb);
+#pragma unroll
+            for (int k = 0; k < KIT; ++k) xa[k] = xb[k];
+          }
+        }
+        STAMP(8);
+        // ---------------- phase B: this lane's pixels -> its 13 contributions
+        float pl = 0.f;
+        float GR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float GT[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < CH / 64; ++u)
+        if (u * 64 + lane < cn) {
+          const uint32_t ent_b = ent_bs[u];
+          const float cl = cls[u];
+          const int lb = u * 64 + lane;
+          const int p = (int)(ent_b & 0xffffu), f = (int)(ent_b >> 16);
+          const int pi = (int)__umulhi((unsigned)p, P.w_magic), pj = p - pi * P.w;
+          const int a = S - 1 - (pj + P.c0), b = S - 1 - (pi + P.r0);
+          const us4 fv_ = L.fc[f];
+          const int i0 = fv_.x, i1 = fv_.y, i2 = fv_.z;
+          const float g0 = gbuf[3 * lb], g1 = gbuf[3 * lb + 1], g2 = gbuf[3 * lb + 2];
+          float v[9];
+          load_face_verts(L, i0, i1, i2, v);
+          const float px = L.ndc[a], py = L.ndc[b];
+          // coverage was decided (exactly) by the rasterizer; the quantities below only feed the
+          // 1e-4-tolerance loss and gradient, so reciprocals replace IEEE divisions here
+          const float ia = __builtin_amdgcn_rcpf(face_area_eps(v, P.keps));
+          const float w0 = edge_fn(px, py, v[3], v[4], v[6], v[7]) * ia;
+          const float w1 = edge_fn(px, py, v[6], v[7], v[0], v[1]) * ia;
+          const float w2 = edge_fn(px, py, v[0], v[1], v[3], v[4]) * ia;
+          float b0 = w0, b1 = w1, b2 = w2, iden = 1.0f;
+          if (PERSP) {
+            const float t0 = (w0 * v[5]) * v[8], t1 = (v[2] * w1) * v[8], t2 = (v[2] * v[5]) * w2;
+            iden = __builtin_amdgcn_rcpf((t0 + t1) + t2);
+            b0 = t0 * iden; b1 = t1 * iden; b2 = t2 * iden;
+          }
+          const float obj = (b0 * g0 + b1 * g1) + b2 * g2;
+          float ind;
+          if (RAW) {
+            ind = 1.0f;
+          } else if (P.clutter) {
+            pl += fmaxf(obj, cl) - fmaxf(0.0f, cl);
+            ind = obj > cl ? 1.0f : (obj == cl ? 0.5f : 0.0f);
+          } else {
+            pl += obj;
+            ind = 1.0f;
+          }
+          if (GRAD && ind != 0.0f) {
+            const float up = RAW ? 1.0f : -P.inv_hw * ind;
+            const float gb0 = up * g0, gb1 = up * g1, gb2 = up * g2;
+            float gw0 = gb0, gw1 = gb1, gw2 = gb2, gz0 = 0.f, gz1 = 0.f, gz2 = 0.f;
+            if (PERSP) {
+              const float z0 = v[2], z1 = v[5], z2 = v[8];
+              const float dot = (gb0 * b0 + gb1 * b1) + gb2 * b2;
+              const float gt0 = (gb0 - dot) * iden, gt1 = (gb1 - dot) * iden, gt2 = (gb2 - dot) * iden;
+              gw0 = gt0 * z1 * z2; gw1 = gt1 * z0 * z2; gw2 = gt2 * z0 * z1;
+              gz0 = gt1 * w1 * z2 + gt2 * z1 * w2;
+              gz1 = gt0 * w0 * z2 + gt2 * z0 * w2;
+              gz2 = gt0 * w0 * z1 + gt1 * z0 * w1;
+            }
+            const float gE0 = gw0 * ia, gE1 = gw1 * ia, gE2 = gw2 * ia;
+            const float gA = -((gw0 * w0 + gw1 * w1) + gw2 * w2) * ia;
+            float gv[9];
+            gv[0] = gE1 * (v[7] - py) + gE2 * (py - v[4]) + gA * (v[7] - v[4]);
+            gv[1] = gE1 * (px - v[6]) + gE2 * (v[3] - px) + gA * (v[3] - v[6]);
+            gv[2] = gz0;
+            gv[3] = gE0 * (py - v[7]) + gE2 * (v[1] - py) + gA * (v[1] - v[7]);
+            gv[4] = gE0 * (v[6] - px) + gE2 * (px - v[0]) + gA * (v[6] - v[0]);
+            gv[5] = gz1;
+            gv[6] = gE0 * (v[4] - py) + gE1 * (py - v[1]) + gA * (v[4] - v[1]);
+            gv[7] = gE0 * (px - v[3]) + gE1 * (v[0] - px) + gA * (v[0] - v[3]);
+            gv[8] = gz2;
+            const int vi[3] = {i0, i1, i2};
+            const float inv_s = 1.0f / s, T0 = L.ust[U_T], T1 = L.ust[U_T + 1], T2 = L.ust[U_T + 2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const float iz = __builtin_amdgcn_rcpf(v[3 * c + 2]);
+              const float gxc = gv[3 * c] * iz, gyc = gv[3 * c + 1] * iz;
+              const float gzv = gv[3 * c + 2] - (gv[3 * c] * v[3 * c] + gv[3 * c + 1] * v[3 * c + 1]) * iz;
+              const float q0 = s * gxc, q1 = s * gyc, q2 = gzv;
+              // world vertex = (view - T) R^T: accumulate against (view - T) and rotate the 3x3 total once
+              // at the end (no world-space vertex table in LDS)
+              const float zs = v[3 * c + 2] * inv_s;
+              const float X0 = v[3 * c] * zs - T0, X1 = v[3 * c + 1] * zs - T1, X2 = v[3 * c + 2] - T2;
+              (void)vi;
+              GR[0] = fmaf(X0, q0, GR[0]); GR[1] = fmaf(X0, q1, GR[1]); GR[2] = fmaf(X0, q2, GR[2]);
+              GR[3] = fmaf(X1, q0, GR[3]); GR[4] = fmaf(X1, q1, GR[4]); GR[5] = fmaf(X1, q2, GR[5]);
+              GR[6] = fmaf(X2, q0, GR[6]); GR[7] = fmaf(X2, q1, GR[7]); GR[8] = fmaf(X2, q2, GR[8]);
+              GT[0] += q0; GT[1] += q1; GT[2] += q2;
+            }
+          }
+        }
+        // chunk partials (fixed DPP tree), written by one lane
+        {
+          float pv[13];
+          pv[0] = wave_sum_dpp(pl);
+          if (GRAD) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) pv[1 + i] = wave_sum_dpp(GR[i]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) pv[10 + i] = wave_sum_dpp(GT[i]);
+          }
+          if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) part[ccur * 16 + i] = pv[i];
+          }
+        }
+        STAMP(9);
+        ccur = cnxt;
+        cnxt = grab();
+      }
+    }
+    STAMP(4);
+    __syncthreads();  // all chunks of the band are done
+    if (SCORE) {
+      // chunk partials -> running totals, in chunk order, one lane per total (wave 0 owns U_TOT)
+      constexpr int NPB = GRAD ? 13 : 1;
+      if (wave == 0 && lane < NPB) {
+        const float *part = (const float *)L.zb;
+        const int nchunks = plan_chunks(ntot).nchunks;
+        float t = L.ust[U_TOT + lane];
+        for (int c = 0; c < nchunks; ++c) t += part[c * 16 + lane];
+        L.ust[U_TOT + lane] = t;
+      }
+      if (tid == 0) *(int *)(L.ust + U_CTR) = 0;
+    }
+    __syncthreads();  // band's z-buffer / lists are reused by the next band
+    STAMP(5);
+  };
+
+
+  if (PRE) {
+    // pre-rendered pose (grid search): the face-major list was built once per (mesh, pose) by
+    // prerender_kernel; it is consumed in pieces of at most `cap` entries
+    for (int pb = 0; pb < emit.pre_cnt; pb += P.cap) {
+      const int ntot = min(P.cap, emit.pre_cnt - pb);
+      for (int i = tid; i < ntot; i += NT) L.list[i] = emit.pre_list[pb + i];
+      ncov += (tid == 0) ? ntot : 0;
+      __syncthreads();
+      consume(ntot, ebase);
+      ebase += ntot;
+    }
+  } else if (!empty_box) {
     const int rows_per_band = P.cap / bw;  // >= 1 because cap >= w >= bw
     for (int bb = b_lo; bb <= b_hi; bb += rows_per_band) {
       const int nr = min(rows_per_band, b_hi - bb + 1);
@@ -594,294 +913,27 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       ncov += (tid == 0) ? ntot : 0;
       __syncthreads();
       STAMP(3);
-      if (!SCORE) {
-        // standalone rasterizer: emit pix_to_face / bary / zbuf for covered pixels
-        for (int e = tid; e < ntot; e += NT) {
-          const uint32_t ent = L.list[e];
-          const int p = (int)(ent & 0xffffu), f = (int)(ent >> 16);
-          const int i = (int)__umulhi((unsigned)p, P.w_magic), j = p - i * P.w;
-          const int a = S - 1 - (j + P.c0), b = S - 1 - (i + P.r0);
-          const us4 fv_ = L.fc[f];
-          float v[9];
-          load_face_verts(L, fv_.x, fv_.y, fv_.z, v);
-          Frag fr;
-          fr.b0 = fr.b1 = fr.b2 = fr.pz = -1.0f;
-          frag_eval<PERSP>(L.ndc[a], L.ndc[b], v, face_area_eps(v, P.keps), fr);
-          emit.p2f[p] = f;
-          emit.bary[3 * p] = fr.b0; emit.bary[3 * p + 1] = fr.b1; emit.bary[3 * p + 2] = fr.b2;
-          if (emit.zbuf) emit.zbuf[p] = fr.pz;
-        }
-      } else {
-        // ---- 3. fused interpolate + score (+ backward).  Each wave owns a contiguous
-        // segment of the face-major list and works through it in chunks of 64 pixels:
-        //  phase A (LPP lanes per pixel): 16-byte loads of the pixel's feature row and of
-        //    the face's three vertex-bank rows, three D-long dot products reduced with
-        //    DPP, results parked in a wave-private LDS buffer.  A lane group walks
-        //    consecutive list entries and re-reads a bank row only when that vertex slot
-        //    changes (the two triangles of a cuboid cell share two of their three slots).
-        //    The next entry's feature row is always in flight (ping-pong registers); the
-        //    prefetch is unconditional because a conditional load would make the compiler
-        //    drain vmcnt to zero every iteration.
-        //  phase B (one lane per pixel): barycentrics, object score, loss term and the
-        //    hand-derived backward to dL/dR, dL/dT accumulators.
-        // Both phases are wave-local (LDS operations of one wave complete in order), so
-        // there is no workgroup barrier inside this loop.
-        // Chunks are handed out dynamically (LDS counter) so that no wave idles at the band barrier;
-        // every chunk leaves its 14 partial sums in LDS (the z-buffer is dead by now and hosts them)
-        // and they are added up in chunk order afterwards, so the totals do not depend on which
-        // wave ran which chunk.
-        constexpr int GPW = 64 / LPP;
-        constexpr int NP = GRAD ? 13 : 1;  // partials per chunk: loss term, dL/dR (9), dL/dT (3)
-        const int gl = lane & (LPP - 1), grp = lane / LPP;
-        const ChunkPlan cp = plan_chunks(ntot);
-        const int nchunks = cp.nchunks;
-        float *part = (float *)L.zb;                                  // [nchunks][16]
-        uint4 *rec = (uint4 *)(part + (size_t)max_chunks(P.cap) * 16) + wave * CH;               // [NW][CH]
-        float *gbuf = (float *)((uint4 *)(part + (size_t)max_chunks(P.cap) * 16) + NW * CH) + wave * (CH * 3);  // [NW][CH*3]
-        int *ctr = (int *)(L.ust + U_CTR);
-        auto grab = [&]() {
-          int v = 0;
-          if (lane == 0) v = atomicAdd(ctr, 1);
-          return __builtin_amdgcn_readfirstlane(v);
-        };
-        // rows are addressed as uniform base + 32-bit byte offset (feature window and bank are < 4 GiB)
-        typedef const __attribute__((address_space(1))) char *gbytep;
-        const gbytep fbytes = (gbytep)gfeat, bbytes = (gbytep)bank;
-        const uint32_t gl16 = (uint32_t)gl * 16u;
-        auto first_off = [&](int c) {  // byte offset of the feature row of this lane group's first entry in chunk c
-          int cb_, cn_;
-          chunk_range(cp, ntot, c, cb_, cn_);
-          const int per_ = (cn_ + GPW - 1) / GPW;
-          return (L.list[cb_ + min(grp * per_, cn_ - 1)] & 0xffffu) * (uint32_t)(D * 4) + gl16;
-        };
-        int ccur = grab(), cnxt = grab();
-        f4 xa[KIT], xb[KIT];  // ping-pong: current / next feature-row fragments
-        if (ccur < nchunks) {
-          const gf4p Fp = (gf4p)(fbytes + first_off(ccur));
-#pragma unroll
-          for (int k = 0; k < KIT; ++k) xa[k] = __builtin_nontemporal_load(Fp + LPP * k);
-        }
-        while (ccur < nchunks) {
-          int cb, cn;
-          chunk_range(cp, ntot, ccur, cb, cn);
-          const int per = (cn + GPW - 1) / GPW;  // entries per lane group in this chunk
-          // ---------------- records (one lane per entry): everything phase A needs to know about an entry
-          // -- feature-row byte offset and the three bank rows -- is worked out once here, 64 entries per
-          // instruction, instead of by every lane of a group inside the loop.  The same pass fetches this
-          // lane's phase-B list entries and clutter scores (they land during phase A).
-          uint32_t ent_bs[CH / 64];
-          float cls[CH / 64];
-#pragma unroll
-          for (int u = 0; u < CH / 64; ++u) {
-            const uint32_t ent = L.list[cb + min(u * 64 + lane, cn - 1)];
-            ent_bs[u] = ent;
-            cls[u] = (P.clutter && clu) ? gclu[ent & 0xffffu] : 0.0f;
-            if (u * 64 < cn) {
-              const us4 fv_ = L.fc[ent >> 16];
-              rec[u * 64 + lane] = uint4{(ent & 0xffffu) * (uint32_t)(D * 4), (uint32_t)fv_.x | ((uint32_t)fv_.y << 16),
-                                         (uint32_t)fv_.z, 0u};
-            }
-          }
-          // ---------------- phase A
-          {
-            // first feature row of this group in the wave's next chunk (or a harmless reload at the very end)
-            const int e0 = grp * per;
-            uint4 R0 = rec[min(e0, cn - 1)], R1 = rec[min(e0 + 1, cn - 1)];  // records run two entries ahead
-            const uint32_t off_next_chunk = cnxt < nchunks ? first_off(cnxt) : R0.x + gl16;
-            int i0 = -1, i1 = -1, i2 = -1;
-            f4 y0[KIT], y1[KIT], y2[KIT];
-#pragma unroll
-            for (int k = 0; k < KIT; ++k) y0[k] = y1[k] = y2[k] = f4{0.f, 0.f, 0.f, 0.f};
-            auto body = [&](int j, f4(&xc)[KIT], f4(&xnext)[KIT]) {
-              const int el = e0 + j;
-              const uint4 R2 = rec[min(el + 2, cn - 1)];
-              // 1st: the loads this entry depends on (bank rows of a changed vertex slot) ...
-              const int n0 = (int)(R0.y & 0xffffu), n1 = (int)(R0.y >> 16), n2 = (int)R0.z;
-              if (n0 != i0) {
-                i0 = n0;
-                const gf4p B = (gf4p)(bbytes + ((uint32_t)n0 * (uint32_t)(D * 4) + gl16));
-#pragma unroll
-                for (int k = 0; k < KIT; ++k) y0[k] = (GRAD && (NEMO_ABL & 2)) ? f4{(float)n0, 1.f, 2.f, 3.f} : B[LPP * k];
-              }
-              if (n1 != i1) {
-                i1 = n1;
-                const gf4p B = (gf4p)(bbytes + ((uint32_t)n1 * (uint32_t)(D * 4) + gl16));
-#pragma unroll
-                for (int k = 0; k < KIT; ++k) y1[k] = (GRAD && (NEMO_ABL & 2)) ? f4{(float)n1, 1.f, 2.f, 3.f} : B[LPP * k];
-              }
-              if (n2 != i2) {
-                i2 = n2;
-                const gf4p B = (gf4p)(bbytes + ((uint32_t)n2 * (uint32_t)(D * 4) + gl16));
-#pragma unroll
-                for (int k = 0; k < KIT; ++k) y2[k] = (GRAD && (NEMO_ABL & 2)) ? f4{(float)n2, 1.f, 2.f, 3.f} : B[LPP * k];
-              }
-              // ... 2nd: the next entry's feature row, which stays in flight (vmcnt is in order)
-              {
-                const uint32_t offn = (j + 1 < per) ? R1.x + gl16 : off_next_chunk;
-                const gf4p Fp = (gf4p)(fbytes + offn);
-#pragma unroll
-                for (int k = 0; k < KIT; ++k)
-                  xnext[k] = (GRAD && (NEMO_ABL & 1)) ? f4{(float)offn, 1.f, 2.f, 3.f} : __builtin_nontemporal_load(Fp + LPP * k);
-              }
-              f4 A0 = xc[0] * y0[0], A1 = xc[0] * y1[0], A2 = xc[0] * y2[0];
-#pragma unroll
-              for (int k = 1; k < KIT; ++k) {
-                A0 = __builtin_elementwise_fma(xc[k], y0[k], A0);
-                A1 = __builtin_elementwise_fma(xc[k], y1[k], A1);
-                A2 = __builtin_elementwise_fma(xc[k], y2[k], A2);
-              }
-              float s0 = (A0.x + A0.y) + (A0.z + A0.w), s1 = (A1.x + A1.y) + (A1.z + A1.w),
-                    s2 = (A2.x + A2.y) + (A2.z + A2.w);
-              if (LPP >= 16) {
-                if (LPP >= 32) {
-                  s0 += __shfl_xor(s0, 16); s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
-                }
-                const float w = sum3_row16(s0, s1, s2);  // quad q of the row holds the total of value q (q < 3)
-                if (el < cn && (gl & 3) == 0 && gl < 12) gbuf[3 * el + (gl >> 2)] = w;
-              } else {
-                const float g0 = sum8(s0), g1 = sum8(s1), g2 = sum8(s2);
-                if (gl == 0 && el < cn) {
-                  gbuf[3 * el] = g0; gbuf[3 * el + 1] = g1; gbuf[3 * el + 2] = g2;
-                }
-              }
-              R0 = R1; R1 = R2;
-            };
-            int j = (GRAD && (NEMO_ABL & 4)) ? per : 0;
-            for (; j + 1 < per; j += 2) {
-              body(j, xa, xb);
-              body(j + 1, xb, xa);
-            }
-            if (j < per) {  // odd tail: one more entry, then put the prefetched row back in xa
-              body(j, xa, xb);
-#pragma unroll
-              for (int k = 0; k < KIT; ++k) xa[k] = xb[k];
-            }
-          }
-          STAMP(8);
-          // ---------------- phase B: this lane's pixels -> its 13 contributions
-          float pl = 0.f;
-          float GR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          float GT[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-          for (int u = 0; u < CH / 64; ++u)
-          if (u * 64 + lane < cn) {
-            const uint32_t ent_b = ent_bs[u];
-            const float cl = cls[u];
-            const int lb = u * 64 + lane;
-            const int p = (int)(ent_b & 0xffffu), f = (int)(ent_b >> 16);
-            const int pi = (int)__umulhi((unsigned)p, P.w_magic), pj = p - pi * P.w;
-            const int a = S - 1 - (pj + P.c0), b = S - 1 - (pi + P.r0);
-            const us4 fv_ = L.fc[f];
-            const int i0 = fv_.x, i1 = fv_.y, i2 = fv_.z;
-            const float g0 = gbuf[3 * lb], g1 = gbuf[3 * lb + 1], g2 = gbuf[3 * lb + 2];
-            float v[9];
-            load_face_verts(L, i0, i1, i2, v);
-            const float px = L.ndc[a], py = L.ndc[b];
-            // coverage was decided (exactly) by the rasterizer; the quantities below only feed the
-            // 1e-4-tolerance loss and gradient, so reciprocals replace IEEE divisions here
-            const float ia = __builtin_amdgcn_rcpf(face_area_eps(v, P.keps));
-            const float w0 = edge_fn(px, py, v[3], v[4], v[6], v[7]) * ia;
-            const float w1 = edge_fn(px, py, v[6], v[7], v[0], v[1]) * ia;
-            const float w2 = edge_fn(px, py, v[0], v[1], v[3], v[4]) * ia;
-            float b0 = w0, b1 = w1, b2 = w2, iden = 1.0f;
-            if (PERSP) {
-              const float t0 = (w0 * v[5]) * v[8], t1 = (v[2] * w1) * v[8], t2 = (v[2] * v[5]) * w2;
-              iden = __builtin_amdgcn_rcpf((t0 + t1) + t2);
-              b0 = t0 * iden; b1 = t1 * iden; b2 = t2 * iden;
-            }
-            const float obj = (b0 * g0 + b1 * g1) + b2 * g2;
-            float ind;
-            if (RAW) {
-              ind = 1.0f;
-            } else if (P.clutter) {
-              pl += fmaxf(obj, cl) - fmaxf(0.0f, cl);
-              ind = obj > cl ? 1.0f : (obj == cl ? 0.5f : 0.0f);
-            } else {
-              pl += obj;
-              ind = 1.0f;
-            }
-            if (GRAD && ind != 0.0f) {
-              const float up = RAW ? 1.0f : -P.inv_hw * ind;
-              const float gb0 = up * g0, gb1 = up * g1, gb2 = up * g2;
-              float gw0 = gb0, gw1 = gb1, gw2 = gb2, gz0 = 0.f, gz1 = 0.f, gz2 = 0.f;
-              if (PERSP) {
-                const float z0 = v[2], z1 = v[5], z2 = v[8];
-                const float dot = (gb0 * b0 + gb1 * b1) + gb2 * b2;
-                const float gt0 = (gb0 - dot) * iden, gt1 = (gb1 - dot) * iden, gt2 = (gb2 - dot) * iden;
-                gw0 = gt0 * z1 * z2; gw1 = gt1 * z0 * z2; gw2 = gt2 * z0 * z1;
-                gz0 = gt1 * w1 * z2 + gt2 * z1 * w2;
-                gz1 = gt0 * w0 * z2 + gt2 * z0 * w2;
-                gz2 = gt0 * w0 * z1 + gt1 * z0 * w1;
-              }
-              const float gE0 = gw0 * ia, gE1 = gw1 * ia, gE2 = gw2 * ia;
-              const float gA = -((gw0 * w0 + gw1 * w1) + gw2 * w2) * ia;
-              float gv[9];
-              gv[0] = gE1 * (v[7] - py) + gE2 * (py - v[4]) + gA * (v[7] - v[4]);
-              gv[1] = gE1 * (px - v[6]) + gE2 * (v[3] - px) + gA * (v[3] - v[6]);
-              gv[2] = gz0;
-              gv[3] = gE0 * (py - v[7]) + gE2 * (v[1] - py) + gA * (v[1] - v[7]);
-              gv[4] = gE0 * (v[6] - px) + gE2 * (px - v[0]) + gA * (v[6] - v[0]);
-              gv[5] = gz1;
-              gv[6] = gE0 * (v[4] - py) + gE1 * (py - v[1]) + gA * (v[4] - v[1]);
-              gv[7] = gE0 * (px - v[3]) + gE1 * (v[0] - px) + gA * (v[0] - v[3]);
-              gv[8] = gz2;
-              const int vi[3] = {i0, i1, i2};
-#pragma unroll
-              for (int c = 0; c < 3; ++c) {
-                const float iz = __builtin_amdgcn_rcpf(v[3 * c + 2]);
-                const float gxc = gv[3 * c] * iz, gyc = gv[3 * c + 1] * iz;
-                const float gzv = gv[3 * c + 2] - (gv[3 * c] * v[3 * c] + gv[3 * c + 1] * v[3 * c + 1]) * iz;
-                const float q0 = s * gxc, q1 = s * gyc, q2 = gzv;
-                const f4 Xw = L.xw[vi[c]];
-                const float X0 = Xw.x, X1 = Xw.y, X2 = Xw.z;
-                GR[0] = fmaf(X0, q0, GR[0]); GR[1] = fmaf(X0, q1, GR[1]); GR[2] = fmaf(X0, q2, GR[2]);
-                GR[3] = fmaf(X1, q0, GR[3]); GR[4] = fmaf(X1, q1, GR[4]); GR[5] = fmaf(X1, q2, GR[5]);
-                GR[6] = fmaf(X2, q0, GR[6]); GR[7] = fmaf(X2, q1, GR[7]); GR[8] = fmaf(X2, q2, GR[8]);
-                GT[0] += q0; GT[1] += q1; GT[2] += q2;
-              }
-            }
-          }
-          // chunk partials (fixed DPP tree), written by one lane
-          {
-            float pv[13];
-            pv[0] = wave_sum_dpp(pl);
-            if (GRAD) {
-#pragma unroll
-              for (int i = 0; i < 9; ++i) pv[1 + i] = wave_sum_dpp(GR[i]);
-#pragma unroll
-              for (int i = 0; i < 3; ++i) pv[10 + i] = wave_sum_dpp(GT[i]);
-            }
-            if (lane == 0) {
-#pragma unroll
-              for (int i = 0; i < NP; ++i) part[ccur * 16 + i] = pv[i];
-            }
-          }
-          STAMP(9);
-          ccur = cnxt;
-          cnxt = grab();
-        }
-      }
-      STAMP(4);
-      __syncthreads();  // all chunks of the band are done
-      if (SCORE) {
-        // chunk partials -> running totals, in chunk order, one lane per total (wave 0 owns U_TOT)
-        constexpr int NPB = GRAD ? 13 : 1;
-        if (wave == 0 && lane < NPB) {
-          const float *part = (const float *)L.zb;
-          const int nchunks = plan_chunks(ntot).nchunks;
-          float t = L.ust[U_TOT + lane];
-          for (int c = 0; c < nchunks; ++c) t += part[c * 16 + lane];
-          L.ust[U_TOT + lane] = t;
-        }
-        if (tid == 0) *(int *)(L.ust + U_CTR) = 0;
-      }
-      __syncthreads();  // band's z-buffer / lists are reused by the next band
-      STAMP(5);
+      consume(ntot, ebase);
+      ebase += ntot;
     }
   }
 
   // ---- 4. totals are already in L.ust[U_TOT..] (chunk partials added in chunk order by wave 0)
-  if (tid == 0) L.ust[U_TOT + T_NCOV] = (float)ncov;
+  if (tid == 0) {
+    L.ust[U_TOT + T_NCOV] = (float)ncov;
+    if (GRAD) {  // dL/dR = R * sum((view - T)^T q)
+      const float *R = L.ust + U_R;
+      float W[9], G[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) W[i] = L.ust[U_TOT + T_GR + i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) G[3 * i + j] = (R[3 * i] * W[j] + R[3 * i + 1] * W[3 + j]) + R[3 * i + 2] * W[6 + j];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) L.ust[U_TOT + T_GR + i] = G[i];
+    }
+  }
   __syncthreads();
   STAMP(6);
 }
@@ -916,7 +968,6 @@ __device__ void loss_constant(const KParams &P, const Lds &L, const float *__res
 __device__ __forceinline__ void load_world_verts(const KParams &P, const Lds &L, const MeshDesc &M) {
   const gi32p gf = as_global(M.faces);
   const gf32p gv = as_global(M.verts);
-  for (int i = threadIdx.x; i < M.V; i += NT) L.xw[i] = f4{gv[3 * i], gv[3 * i + 1], gv[3 * i + 2], 0.0f};
   for (int i = threadIdx.x; i < M.F; i += NT)
     L.fc[i] = us4{(unsigned short)gf[3 * i], (unsigned short)gf[3 * i + 1], (unsigned short)gf[3 * i + 2], 0};
   for (int i = threadIdx.x; i < P.S; i += NT) L.ndc[i] = ndc_of(i, (float)P.S);
@@ -1023,6 +1074,32 @@ __global__ __launch_bounds__(NT, 4) void score_kernel(KParams P, const MeshDesc 
   }
 }
 
+// Pre-render (get_pre_render_samples, code/MeshPoseSolveAll.py:62-82): the coverage of a grid pose
+// depends on the mesh and the pose only, so its face-major list is built once per (mesh, grid, pose)
+// and every image's grid search consumes it.  One workgroup per (pair, pose).
+template <bool PERSP>
+__global__ __launch_bounds__(NT, 4) void prerender_kernel(KParams P, const MeshDesc *meshes, const int32_t *pair_mesh,
+                                                          const int32_t *pair_grid, const float *gridC,
+                                                          const float *gridTheta, int G, uint32_t *list, int32_t *cnt,
+                                                          size_t stride) {
+  const int sl = blockIdx.x / G, g = blockIdx.x % G;
+  const MeshDesc M = meshes[pair_mesh[sl]];
+  const int gi = pair_grid[sl];
+  const Lds L = lds_carve(smem, P);
+  load_world_verts(P, L, M);
+  if (threadIdx.x == 0) {
+    const float *gc = gridC + ((size_t)gi * G + g) * 3;
+    const float Cp[3] = {gc[0], gc[1], gc[2]};
+    Cam cam;
+    ust_set_camera(L, Cp, gridTheta[(size_t)gi * G + g], cam);
+  }
+  __syncthreads();
+  EmitOut e{};
+  e.list_out = list + (size_t)blockIdx.x * stride;
+  eval_pose<128, PERSP, false, false>(P, L, M, nullptr, nullptr, e);
+  if (threadIdx.x == 0) cnt[blockIdx.x] = (int)(block_total(L, T_NCOV) + 0.5f);
+}
+
 // Grid search: one workgroup per (job, grid pose).  Block ids are dealt so that
 // all poses of one image run on the same XCD at about the same time (blocks b
 // and b+8 share an XCD under round-robin dispatch; L2 affinity only, never
@@ -1031,32 +1108,49 @@ template <int D, bool PERSP>
 __global__ __launch_bounds__(NT, 4) void grid_kernel(KParams P, const MeshDesc *meshes, int N, const int32_t *img_idx,
                                                      const int32_t *mesh_idx, const int32_t *grid_idx,
                                                      const float *feat, const float *clu, const float *gridC,
-                                                     const float *gridTheta, int G, float *losses, u64 *counter) {
+                                                     const float *gridTheta, int G, float *losses, u64 *counter,
+                                                     PreStore pre) {
+  const int GB = (G + GRID_POSES_PER_WG - 1) / GRID_POSES_PER_WG;
   const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-  const int n = (k / G) * 8 + xcd, g = k % G;
+  const int n = (k / GB) * 8 + xcd, g0 = (k % GB) * GRID_POSES_PER_WG;
   if (n >= N) return;
-  const MeshDesc M = meshes[mesh_idx ? mesh_idx[n] : 0];
+  const int mi = mesh_idx ? mesh_idx[n] : 0;
+  const MeshDesc M = meshes[mi];
   const int img = img_idx ? img_idx[n] : n;
   const int gi = grid_idx ? grid_idx[n] : 0;
+  const int slot = (pre.slot && gi < MAX_GRIDS) ? pre.slot[mi * MAX_GRIDS + gi] : -1;
   const size_t hw = (size_t)P.h * P.w;
   const float *f = feat + (size_t)img * hw * D;
   const float *c = clu ? clu + (size_t)img * hw : nullptr;
   const Lds L = lds_carve(smem, P);
   load_world_verts(P, L, M);
   loss_constant(P, L, c);
-  if (threadIdx.x == 0) {
-    const float *gc = gridC + ((size_t)gi * G + g) * 3;
-    const float Cp[3] = {gc[0], gc[1], gc[2]};
-    Cam cam;
-    ust_set_camera(L, Cp, gridTheta[(size_t)gi * G + g], cam);
+  u64 ncov_sum = 0;
+  // a workgroup walks a few consecutive poses of its image: the per-image set-up is paid once
+  for (int g = g0; g < min(G, g0 + GRID_POSES_PER_WG); ++g) {
+    if (threadIdx.x == 0) {
+      const float *gc = gridC + ((size_t)gi * G + g) * 3;
+      const float Cp[3] = {gc[0], gc[1], gc[2]};
+      Cam cam;
+      ust_set_camera(L, Cp, gridTheta[(size_t)gi * G + g], cam);
+    }
+    __syncthreads();
+    if (slot >= 0) {  // coverage of this (mesh, pose) was rendered once by nemo_grid_prerender
+      EmitOut e{};
+      const size_t pg = (size_t)slot * G + g;
+      e.pre_list = pre.list + pg * pre.stride;
+      e.pre_cnt = pre.cnt[pg];
+      eval_pose<D, PERSP, false, true, false, true>(P, L, M, f, c, e);
+    } else {
+      EmitOut none{};
+      eval_pose<D, PERSP, false, true>(P, L, M, f, c, none);
+    }
+    if (threadIdx.x == 0) {
+      losses[(size_t)n * G + g] = L.ust[U_K] - P.inv_hw * block_total(L, 0);
+      ncov_sum += (u64)(block_total(L, T_NCOV) + 0.5f);
+    }
   }
-  __syncthreads();
-  EmitOut none{nullptr, nullptr, nullptr};
-  eval_pose<D, PERSP, false, true>(P, L, M, f, c, none);
-  if (threadIdx.x == 0) {
-    losses[(size_t)n * G + g] = L.ust[U_K] - P.inv_hw * block_total(L, 0);
-    if (counter) atomicAdd(counter, (u64)(block_total(L, T_NCOV) + 0.5f));
-  }
+  if (threadIdx.x == 0 && counter) atomicAdd(counter, ncov_sum);
 }
 
 // argmin over the grid losses (first minimum, torch.min semantics at
@@ -1273,6 +1367,11 @@ struct nemo_ctx {
   int adam_steps, adam_cap;
   float beta1, beta2, eps;
   u64 *d_counter;
+  // pre-rendered grid (nemo_grid_prerender)
+  int32_t *d_pre_slot, *d_pre_cnt, *d_pre_pairs;
+  uint32_t *d_pre_list;
+  const float *pre_gridC, *pre_gridT;
+  int pre_G, pre_pairs;
   char err[512];
 };
 
@@ -1301,7 +1400,7 @@ static int plan_lds(nemo_ctx *ctx) {
   const nemo_config &c = ctx->cfg;
   const int vmax = ctx->vmax_seen > 0 ? ((ctx->vmax_seen + 63) & ~63) : 64;
   const int fmax = ctx->fmax_seen > 0 ? ((ctx->fmax_seen + 63) & ~63) : 64;
-  long avail = (long)LDS_BUDGET - (long)vmax * 32 - (long)fmax * 8 -
+  long avail = (long)LDS_BUDGET - (long)vmax * 16 - (long)fmax * 8 -
                ((NW * RED_N + UST_N + c.raster_size + 4) * 4 + 128);
   long cap = avail / (8 + 4);
   if (cap > (long)c.win_h * c.win_w) cap = (long)c.win_h * c.win_w;
@@ -1371,6 +1470,7 @@ int nemo_ctx_create(const nemo_config *cfg, nemo_ctx **out) {
   SET_LDS((score_kernel<256, false>)); SET_LDS((score_kernel<256, true>));
   SET_LDS((grid_kernel<128, false>)); SET_LDS((grid_kernel<128, true>));
   SET_LDS((grid_kernel<256, false>)); SET_LDS((grid_kernel<256, true>));
+  SET_LDS((prerender_kernel<false>)); SET_LDS((prerender_kernel<true>));
   SET_LDS((solve_kernel<128, false>)); SET_LDS((solve_kernel<128, true>));
   SET_LDS((solve_kernel<256, false>)); SET_LDS((solve_kernel<256, true>));
   SET_LDS((interp_bwd_kernel<128, false>)); SET_LDS((interp_bwd_kernel<128, true>));
@@ -1385,6 +1485,7 @@ int nemo_ctx_destroy(nemo_ctx *ctx) {
   hipFree(ctx->d_meshes);
   hipFree(ctx->d_counter);
   hipFree(ctx->d_adam);
+  hipFree(ctx->d_pre_slot); hipFree(ctx->d_pre_cnt); hipFree(ctx->d_pre_pairs); hipFree(ctx->d_pre_list);
   delete ctx;
   return NEMO_OK;
 }
@@ -1501,14 +1602,58 @@ int nemo_grid_search(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const i
     return fail(ctx, NEMO_ERR_ARG, "nemo_grid_search: bad argument");
   if (ctx->cfg.clutter && !d_clu) return fail(ctx, NEMO_ERR_ARG, "nemo_grid_search: clutter loss needs d_clu");
   if (N == 0) return NEMO_OK;
-  const long long blocks = 8LL * ((N + 7) / 8) * G;
+  const long long blocks = 8LL * ((N + 7) / 8) * ((G + GRID_POSES_PER_WG - 1) / GRID_POSES_PER_WG);
   if (blocks > 0x7fffffffLL) return fail(ctx, NEMO_ERR_UNSUPPORTED, "nemo_grid_search: N*G too large for one launch");
+  PreStore pre{nullptr, nullptr, nullptr, 0};
+  if (ctx->pre_pairs > 0 && ctx->pre_G == G && ctx->pre_gridC == d_grid_C && ctx->pre_gridT == d_grid_theta)
+    pre = PreStore{ctx->d_pre_slot, ctx->d_pre_cnt, ctx->d_pre_list, (size_t)ctx->cfg.win_h * ctx->cfg.win_w};
   DISPATCH_DP(grid_kernel, dim3((unsigned)blocks), ctx->P, ctx->d_meshes, N, d_img_idx, d_mesh_idx, d_grid_idx, d_feat,
-              d_clu, d_grid_C, d_grid_theta, G, d_losses, ctx->d_counter);
+              d_clu, d_grid_C, d_grid_theta, G, d_losses, ctx->d_counter, pre);
   HIP_TRY(ctx, hipGetLastError());
   hipLaunchKernelGGL(grid_argmin_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, N, G, d_losses, d_grid_idx,
                      d_grid_C, d_grid_theta, d_C0, d_theta0, d_best);
   HIP_TRY(ctx, hipGetLastError());
+  return NEMO_OK;
+}
+
+int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_grid_theta, int32_t n_grids, int32_t G,
+                        const int32_t *h_pair_mesh, const int32_t *h_pair_grid, int32_t n_pairs, void *stream) {
+  if (!ctx) return fail(nullptr, NEMO_ERR_ARG, "nemo_grid_prerender: null ctx");
+  hipFree(ctx->d_pre_slot); hipFree(ctx->d_pre_cnt); hipFree(ctx->d_pre_pairs); hipFree(ctx->d_pre_list);
+  ctx->d_pre_slot = ctx->d_pre_cnt = ctx->d_pre_pairs = nullptr;
+  ctx->d_pre_list = nullptr;
+  ctx->pre_pairs = 0;
+  if (n_pairs == 0) return NEMO_OK;  // store dropped
+  if (!d_grid_C || !d_grid_theta || !h_pair_mesh || !h_pair_grid || n_pairs < 0 || G <= 0 || n_grids <= 0)
+    return fail(ctx, NEMO_ERR_ARG, "nemo_grid_prerender: bad argument");
+  if (n_grids > MAX_GRIDS) return fail(ctx, NEMO_ERR_UNSUPPORTED, "nemo_grid_prerender: more than %d grids", MAX_GRIDS);
+  std::vector<int32_t> h_slot((size_t)MAX_MESHES * MAX_GRIDS, -1);
+  for (int i = 0; i < n_pairs; ++i) {
+    const int m = h_pair_mesh[i], g = h_pair_grid[i];
+    if (m < 0 || m >= ctx->n_meshes || g < 0 || g >= n_grids)
+      return fail(ctx, NEMO_ERR_ARG, "nemo_grid_prerender: pair %d = (mesh %d, grid %d) out of range", i, m, g);
+    h_slot[m * MAX_GRIDS + g] = i;
+  }
+  const size_t stride = (size_t)ctx->cfg.win_h * ctx->cfg.win_w;
+  HIP_TRY(ctx, hipMalloc(&ctx->d_pre_slot, sizeof(int32_t) * h_slot.size()));
+  HIP_TRY(ctx, hipMalloc(&ctx->d_pre_pairs, sizeof(int32_t) * 2 * n_pairs));
+  HIP_TRY(ctx, hipMalloc(&ctx->d_pre_cnt, sizeof(int32_t) * (size_t)n_pairs * G));
+  HIP_TRY(ctx, hipMalloc(&ctx->d_pre_list, sizeof(uint32_t) * (size_t)n_pairs * G * stride));
+  HIP_TRY(ctx, hipMemcpy(ctx->d_pre_slot, h_slot.data(), sizeof(int32_t) * h_slot.size(), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(ctx->d_pre_pairs, h_pair_mesh, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(ctx->d_pre_pairs + n_pairs, h_pair_grid, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice));
+  const dim3 grid((unsigned)(n_pairs * G));
+  if (ctx->P.persp)
+    hipLaunchKernelGGL((prerender_kernel<true>), grid, dim3(NT), ctx->lds, (hipStream_t)stream, ctx->P, ctx->d_meshes,
+                       ctx->d_pre_pairs, ctx->d_pre_pairs + n_pairs, d_grid_C, d_grid_theta, G, ctx->d_pre_list,
+                       ctx->d_pre_cnt, stride);
+  else
+    hipLaunchKernelGGL((prerender_kernel<false>), grid, dim3(NT), ctx->lds, (hipStream_t)stream, ctx->P, ctx->d_meshes,
+                       ctx->d_pre_pairs, ctx->d_pre_pairs + n_pairs, d_grid_C, d_grid_theta, G, ctx->d_pre_list,
+                       ctx->d_pre_cnt, stride);
+  HIP_TRY(ctx, hipGetLastError());
+  ctx->pre_gridC = d_grid_C; ctx->pre_gridT = d_grid_theta;
+  ctx->pre_G = G; ctx->pre_pairs = n_pairs;
   return NEMO_OK;
 }
 

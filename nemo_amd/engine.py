@@ -189,6 +189,26 @@ class PoseEngine:
             _ptr(best), self._stream()), 'nemo_grid_search')
         return C0, th0, best, losses
 
+    def grid_prerender(self, grid_C, grid_theta, pairs):
+        """get_pre_render_samples (code/MeshPoseSolveAll.py:62-82): render the coverage of every grid pose
+        once per (mesh, grid) pair; later grid_search calls with the SAME grid tensors reuse it.
+        `pairs` = iterable of (mesh id, grid id); an empty list drops the store."""
+        import numpy as np
+        pairs = [(int(m), int(g)) for m, g in pairs]
+        pm = np.ascontiguousarray([p[0] for p in pairs], dtype=np.int32)
+        pg = np.ascontiguousarray([p[1] for p in pairs], dtype=np.int32)
+        if not pairs:
+            _lib.check(self.ctx, self.lib.nemo_grid_prerender(self.ctx, None, None, 0, 0, None, None, 0, self._stream()),
+                       'nemo_grid_prerender')
+            self._pre_keep = None
+            return
+        grid_C, grid_theta = self._f32(grid_C, 'grid_C'), self._f32(grid_theta, 'grid_theta')
+        n_grids, G = (grid_theta.shape[0], grid_theta.shape[-1]) if grid_theta.dim() > 1 else (1, grid_theta.shape[-1])
+        _lib.check(self.ctx, self.lib.nemo_grid_prerender(self.ctx, _ptr(grid_C), _ptr(grid_theta), n_grids, G,
+                                                          pm.ctypes.data, pg.ctypes.data, len(pairs), self._stream()),
+                   'nemo_grid_prerender')
+        self._pre_keep = (grid_C, grid_theta)  # the store is keyed by these device buffers: keep them alive
+
     def solve(self, feat, clu, C0, theta0, img_idx=None, mesh_idx=None, want_trace=False):
         C0, theta0 = self._f32(C0, 'C0'), self._f32(theta0, 'theta0')
         N = C0.shape[0]

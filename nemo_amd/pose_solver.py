@@ -135,6 +135,14 @@ class BatchPoseSolver:
         self.grid_theta = torch.as_tensor(np.stack(self._grids_t)).to(self.device).contiguous()
         return mid
 
+    def prerender(self):
+        """get_pre_render_samples (code/MeshPoseSolveAll.py:62-82), once per set of meshes: every mesh's
+        coverage under each of its grid poses.  A no-op when the store is current."""
+        key = (self.grid_C.data_ptr(), self.grid_theta.data_ptr(), len(self._grids_C))
+        if getattr(self, '_pre_key', None) != key:
+            self.engine.grid_prerender(self.grid_C, self.grid_theta, [(m, m) for m in range(len(self._grids_C))])
+            self._pre_key = key
+
     def clutter_vector(self, clutter_bank: torch.Tensor) -> torch.Tensor:
         """normalize(mean(clutter_bank, 0)) (code/MeshPoseSolveAll.py:207) -> [1, D]."""
         return normalize(torch.mean(clutter_bank, dim=0)).unsqueeze(0).contiguous()
@@ -146,6 +154,7 @@ class BatchPoseSolver:
         eng = self.engine
         clu = None if self.cfg.turn_off_clutter else eng.clutter_score(feats, clutter)
         n_jobs = img_idx.shape[0] if img_idx is not None else feats.shape[0]
+        self.prerender()
         C0, th0, best, _ = eng.grid_search(feats, clu, self.grid_C, self.grid_theta, n_jobs=n_jobs,
                                            img_idx=img_idx, mesh_idx=mesh_idx, grid_idx=mesh_idx)
         out = eng.solve(feats, clu, C0, th0, img_idx=img_idx, mesh_idx=mesh_idx, want_trace=want_trace)

@@ -187,6 +187,33 @@ def test_grid_search(oracle):
 
 
 @pytest.mark.parametrize('persp', [False, True])
+def test_grid_search_prerendered(oracle, persp):
+    """get_pre_render_samples path (code/MeshPoseSolveAll.py:62-100): coverage rendered once per
+    (mesh, pose), then consumed per image.  Same losses (bit for bit: the list the score loop walks is
+    the same) and the same first minimum as the on-the-fly path, and parity with the oracle."""
+    sc = make_scene(n_img=3, perspective_correct=persp)
+    eng = _engine(sc)
+    gC, gth = syn.pose_grid(sc.distance)
+    dC, dth = _dev(gC[None]), _dev(gth[None])
+    feats, clus = _dev(sc.feats), _dev(sc.clus)
+    _, _, best0, losses0 = eng.grid_search(feats, clus, dC, dth)
+    eng.grid_prerender(dC, dth, [(0, 0)])
+    C0, th0, best1, losses1 = eng.grid_search(feats, clus, dC, dth)
+    assert torch.equal(losses0, losses1) and torch.equal(best0, best1)
+    for i in range(3):
+        bo, lo = oracle.grid_search(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[i], sc.clus[i], gC, gth)
+        assert np.abs(losses1[i].cpu().numpy() - lo).max() <= REL * np.abs(lo).max()
+        assert best1[i].item() == bo
+    # another grid buffer (same values): the store does not apply, results are unchanged
+    dC2 = dC.clone()
+    _, _, best2, losses2 = eng.grid_search(feats, clus, dC2, dth)
+    assert torch.equal(losses2, losses1) and torch.equal(best2, best1)
+    eng.grid_prerender(None, None, [])  # drop
+    _, _, best3, losses3 = eng.grid_search(feats, clus, dC, dth)
+    assert torch.equal(losses3, losses1) and torch.equal(best3, best1)
+
+
+@pytest.mark.parametrize('persp', [False, True])
 def test_solve_teacher_forced_and_final_pose(oracle, persp):
     sc = make_scene(n_img=3, perspective_correct=persp)
     eng = _engine(sc)

@@ -44,6 +44,7 @@ if os.environ.get('NEMO_HIP_LIB'):
         print('score split: phaseA %.1f%% phaseB %.1f%% of total' % (100*st[8]/(tot+st[8]+st[9]-st[4]), 100*st[9]/(tot+st[8]+st[9]-st[4])))
         print('phase shares (wave-0 cycles, last solve): ' + ', '.join(f'{n} {100*st[i]/tot:.1f}%' for i, n in enumerate(names)))
 if args.grid:
+    s.prerender()
     for r in range(args.reps):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         eng.grid_search(wl.feats, clu, s.grid_C, s.grid_theta, mesh_idx=wl.mesh_idx, grid_idx=wl.mesh_idx)

@@ -64,6 +64,48 @@ __global__ __launch_bounds__(1024) void k(const float *tab, float *out, int iter
   if (acc == 123.456f) out[threadIdx.x] = acc;
 }
 
+// Streaming shape of the score loop: 4 groups x 16 lanes, two 16-byte loads per 512-byte row, rows picked
+// pseudo-randomly from a table of `nrows` rows (large table: HBM; small: L2), DEPTH rows in flight per wave.
+template <int DEPTH>
+__global__ __launch_bounds__(1024) void ks(const float *tab, float *out, int iters, unsigned nrows_mask) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, gl = lane & 15;
+  const char *base = (const char *)tab;
+  unsigned r = (blockIdx.x * 16 + wave) * 4 + g;
+  f4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < iters; ++i) {
+    f4 v[DEPTH][2];
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) {
+      r = r * 1664525u + 1013904223u;
+      const gf4p p = (gf4p)(base + (size_t)((r >> 8) & nrows_mask) * ROWB) + gl;
+      v[u][0] = __builtin_nontemporal_load(p);
+      v[u][1] = __builtin_nontemporal_load(p + 16);
+    }
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) acc += v[u][0] * v[u][1];
+  }
+  if (acc.x == 123.456f) out[threadIdx.x] = acc.x + acc.y + acc.z + acc.w;
+}
+template <int DEPTH>
+void runs(const float *tab, float *out, unsigned nrows, const char *name, int grid = 256) {
+  const int iters = 4000 / DEPTH;
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  ks<DEPTH><<<grid, 1024>>>(tab, out, 4, nrows - 1);
+  hipDeviceSynchronize();
+  hipEventRecord(a);
+  ks<DEPTH><<<grid, 1024>>>(tab, out, iters, nrows - 1);
+  hipEventRecord(b);
+  hipEventSynchronize(b);
+  float ms = 0;
+  hipEventElapsedTime(&ms, a, b);
+  const double instr_per_cu = (double)iters * DEPTH * 2 * 16;
+  const double bytes = (double)grid * instr_per_cu * 1024;
+  printf("stream depth %d %-22s grid %3d %8.3f ms  %6.1f ns/instr/CU (%.1f cyc)  %.0f GB/s total, %.1f GB/s/CU\n", DEPTH, name, grid, ms,
+         ms * 1e6 / instr_per_cu, ms * 1e6 / instr_per_cu * 2.4, bytes / ms / 1e6, bytes / ms / 1e6 / grid);
+}
+
 template <int MODE>
 void run(const float *tab, float *out, const char *name) {
   const int iters = 2000, grid = 256;
@@ -98,5 +140,21 @@ int main() {
   run<8>(tab, out, "  same, 1 of 4 groups active");
   run<9>(tab, out, "2 groups x 32 lanes x16B");
   run<10>(tab, out, "  same, 1 of 2 groups active");
+  float *big;
+  const unsigned big_rows = 1u << 20;  // 512 MiB
+  hipMalloc(&big, (size_t)big_rows * ROWB);
+  hipMemset(big, 0, (size_t)big_rows * ROWB);
+  runs<1>(big, out, big_rows, "HBM (512 MiB)");
+  runs<2>(big, out, big_rows, "HBM (512 MiB)");
+  runs<4>(big, out, big_rows, "HBM (512 MiB)");
+  runs<8>(big, out, big_rows, "HBM (512 MiB)");
+  runs<2>(big, out, big_rows, "HBM (512 MiB)", 64);
+  runs<8>(big, out, big_rows, "HBM (512 MiB)", 64);
+  runs<1>(big, out, 1u << 15, "MALL/L2 (16 MiB)");
+  runs<2>(big, out, 1u << 15, "MALL/L2 (16 MiB)");
+  runs<8>(big, out, 1u << 15, "MALL/L2 (16 MiB)");
+  runs<1>(big, out, 1u << 12, "L2 (2 MiB)");
+  runs<2>(big, out, 1u << 12, "L2 (2 MiB)");
+  runs<8>(big, out, 1u << 12, "L2 (2 MiB)");
   return 0;
 }
