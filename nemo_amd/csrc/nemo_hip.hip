@@ -48,7 +48,7 @@ constexpr int U_R = 0, U_T = 9, U_P = 12, U_M = 16, U_V = 20, U_K = 24, U_CTR = 
 // block totals: [0] loss term, [1..9] dL/dR, [10..12] dL/dT, [13] covered pixels
 constexpr int T_LOSS = 0, T_GR = 1, T_GT = 10, T_NCOV = 13;
 constexpr int MAX_MESHES = 1024;
-constexpr int LDS_BUDGET = 160 * 1024 / (1024 / NT);  // the workgroups resident on a CU share its 160 KiB
+constexpr int LDS_BUDGET = 160 * 1024 / (1024 / NT) - (NT < 1024 ? 512 : 0);  // the workgroups resident on a CU share its 160 KiB
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
@@ -350,6 +350,7 @@ struct Lds {
   u64 *zb;               // [cap] packed z-buffer
   f4 *sv;                // [vmax] screen verts (u, t, z_view, -)
   us4 *fc;               // [fmax] face vertex ids (i0, i1, i2, -) as 16-bit
+  us4 *finfo;            // [fmax] per face, per band: box (a_lo, a_hi, b_lo, b_hi) of its fragments
   float *ndc;            // [S] pixel-centre NDC coordinate of flipped index a: PixToNdc(a, S)
   uint32_t *list;        // [cap] covered pixels, face-major: (face id << 16) | window pixel index
   float *red;            // [NW][RED_N]
@@ -390,8 +391,8 @@ __host__ __device__ inline size_t zb_region_bytes(int cap) {
   return ((a > b ? a : b) + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t lds_bytes(int cap, int vmax, int fmax, int wmax, int S) {
-  size_t b = zb_region_bytes(cap) + (size_t)cap * 4 + (size_t)vmax * 16 + (size_t)fmax * 8;
-  b += (NW * RED_N + UST_N + ((S + 3) & ~3)) * 4 + 64;
+  size_t b = zb_region_bytes(cap) + (size_t)cap * 4 + (size_t)vmax * 16 + (size_t)fmax * 16;
+  b += (NW * RED_N + UST_N + ((S + 11) & ~3)) * 4 + 64;
   (void)wmax;
   return (b + 15) & ~(size_t)15;
 }
@@ -401,10 +402,11 @@ __device__ __forceinline__ Lds lds_carve(unsigned char *base, const KParams &P) 
   L.zb = (u64 *)base;
   L.sv = (f4 *)(base + (size_t)P.zb_bytes);
   L.fc = (us4 *)(L.sv + P.vmax);
-  L.list = (uint32_t *)(L.fc + P.fmax);
+  L.finfo = L.fc + P.fmax;
+  L.list = (uint32_t *)(L.finfo + P.fmax);
   L.red = (float *)(L.list + P.cap);
   L.ust = L.red + NW * RED_N;
-  L.ndc = L.ust + UST_N;
+  L.ndc = L.ust + UST_N + 2;  // indices -2 .. S+1
   return L;
 }
 
@@ -504,15 +506,18 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
     float f = ((fmaxf(fminf(vmax_, 4.0f), -4.0f) + 1.0f) * Sf - 1.0f) * 0.5f;
     return (int)ceilf(f) + 1;
   };
-  // [lo, hi] = indices i in [clip_lo, clip_hi] with vmin <= ndc[i] <= vmax, exactly
-  // (ndc[] is monotone; the estimate is off by at most one, the loops fix it up)
+  // [lo, hi] = indices i in [clip_lo, clip_hi] with vmin <= ndc[i] <= vmax, exactly: ndc[] is monotone
+  // and the closed-form estimates floor(f) / ceil(f) are within [0, +2] / [-2, 0] of the answer
+  // (checked exhaustively in tests/test_host_cpu.py), so three table probes each settle it without a
+  // loop.  The table carries two extra entries on either side (indices -2 .. S+1).
   auto exact_range = [&](float vmin, float vmax_, int clip_lo, int clip_hi, int &lo, int &hi) {
-    lo = min(max(lo_idx(vmin) + 1, clip_lo), clip_hi + 1);
-    hi = max(min(hi_idx(vmax_) - 1, clip_hi), clip_lo - 1);
-    while (lo > clip_lo && L.ndc[lo - 1] >= vmin) --lo;
-    while (lo <= hi && L.ndc[lo] < vmin) ++lo;
-    while (hi < clip_hi && L.ndc[hi + 1] <= vmax_) ++hi;
-    while (hi >= lo && L.ndc[hi] > vmax_) --hi;
+    const int e = lo_idx(vmin) + 1, ec = hi_idx(vmax_) - 1;  // floor(f(vmin)), ceil(f(vmax))
+    auto at = [&](int i) { return L.ndc[min(max(i, -2), S + 1)]; };
+    const float l0 = at(e - 1), l1 = at(e), l2 = at(e + 1), h0 = at(ec + 1), h1 = at(ec), h2 = at(ec - 1);
+    lo = (e - 1) + (int)(l0 < vmin) + (int)(l1 < vmin) + (int)(l2 < vmin);
+    hi = (ec + 1) - (int)(h0 > vmax_) - (int)(h1 > vmax_) - (int)(h2 > vmax_);
+    lo = min(max(lo, clip_lo), clip_hi + 1);
+    hi = max(min(hi, clip_hi), clip_lo - 1);
   };
   // workgroup-uniform values read back from LDS live in VGPRs unless told otherwise
   const int a_lo = __builtin_amdgcn_readfirstlane(max(lo_idx(umin), a_w0));
@@ -842,28 +847,38 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       // ---- 2b. face-parallel rasterisation (one thread per face)
       for (int f = tid; f < F; f += NT) {
         const us4 fv_ = L.fc[f];
-          const int i0 = fv_.x, i1 = fv_.y, i2 = fv_.z;
+        const int i0 = fv_.x, i1 = fv_.y, i2 = fv_.z;
         float v[9];
         load_face_verts(L, i0, i1, i2, v);
-        if (face_degenerate(v, P.keps)) continue;
-        const float xmin = fminf(fminf(v[0], v[3]), v[6]), xmax = fmaxf(fmaxf(v[0], v[3]), v[6]);
-        const float ymin = fminf(fminf(v[1], v[4]), v[7]), ymax = fmaxf(fmaxf(v[1], v[4]), v[7]);
-        // exact index ranges of the pixel centres inside the face's bounding box (the test
-        // PyTorch3D applies per pixel), clipped to the object box / band
-        int fa_lo, fa_hi, fb_lo, fb_hi;
-        exact_range(xmin, xmax, a_lo, a_hi, fa_lo, fa_hi);
-        exact_range(ymin, ymax, bb, bb + nr - 1, fb_lo, fb_hi);
-        if (fa_lo > fa_hi || fb_lo > fb_hi) continue;
-        const float area = face_area_eps(v, P.keps);
-        for (int b = fb_lo; b <= fb_hi; ++b) {
-          const float py = L.ndc[b];
-          for (int a = fa_lo; a <= fa_hi; ++a) {
-            Frag fr;
-            if (!frag_eval<PERSP>(L.ndc[a], py, v, area, fr)) continue;
-            const u64 key = ((u64)__float_as_uint(fr.pz) << 32) | (u64)(uint32_t)f;
-            atomicMin(&L.zb[(b - bb) * bw + (a - a_lo)], key);
+        // box of the pixels where this face produced a fragment (empty: lo > hi); the list walks
+        // below look only there
+        int ha_lo = 1, ha_hi = 0, hb_lo = 1, hb_hi = 0;
+        if (!face_degenerate(v, P.keps)) {
+          const float xmin = fminf(fminf(v[0], v[3]), v[6]), xmax = fmaxf(fmaxf(v[0], v[3]), v[6]);
+          const float ymin = fminf(fminf(v[1], v[4]), v[7]), ymax = fmaxf(fmaxf(v[1], v[4]), v[7]);
+          // exact index ranges of the pixel centres inside the face's bounding box (the test
+          // PyTorch3D applies per pixel), clipped to the object box / band
+          int fa_lo, fa_hi, fb_lo, fb_hi;
+          exact_range(xmin, xmax, a_lo, a_hi, fa_lo, fa_hi);
+          exact_range(ymin, ymax, bb, bb + nr - 1, fb_lo, fb_hi);
+          if (fa_lo <= fa_hi && fb_lo <= fb_hi) {
+            const float area = face_area_eps(v, P.keps);
+            ha_lo = hb_lo = 0x7fff; ha_hi = hb_hi = -1;
+            for (int b = fb_lo; b <= fb_hi; ++b) {
+              const float py = L.ndc[b];
+              for (int a = fa_lo; a <= fa_hi; ++a) {
+                Frag fr;
+                if (!frag_eval<PERSP>(L.ndc[a], py, v, area, fr)) continue;
+                const u64 key = ((u64)__float_as_uint(fr.pz) << 32) | (u64)(uint32_t)f;
+                atomicMin(&L.zb[(b - bb) * bw + (a - a_lo)], key);
+                ha_lo = min(ha_lo, a); ha_hi = max(ha_hi, a);
+                hb_lo = min(hb_lo, b); hb_hi = max(hb_hi, b);
+              }
+            }
+            if (ha_hi < 0) { ha_lo = hb_lo = 1; ha_hi = hb_hi = 0; }
           }
         }
+        L.finfo[f] = us4{(unsigned short)ha_lo, (unsigned short)ha_hi, (unsigned short)hb_lo, (unsigned short)hb_hi};
       }
       __syncthreads();
       STAMP(2);
@@ -877,11 +892,8 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       const int fbeg = min(F, tid * fpl), fend = min(F, fbeg + fpl);
       auto walk = [&](auto &&visit) {
         for (int f = fbeg; f < fend; ++f) {
-          const us4 fv_ = L.fc[f];
-          const f4 s0 = L.sv[fv_.x], s1 = L.sv[fv_.y], s2 = L.sv[fv_.z];
-          int fa_lo, fa_hi, fb_lo, fb_hi;
-          exact_range(fminf(fminf(s0.x, s1.x), s2.x), fmaxf(fmaxf(s0.x, s1.x), s2.x), a_lo, a_hi, fa_lo, fa_hi);
-          exact_range(fminf(fminf(s0.y, s1.y), s2.y), fmaxf(fmaxf(s0.y, s1.y), s2.y), bb, bb + nr - 1, fb_lo, fb_hi);
+          const us4 fi = L.finfo[f];
+          const int fa_lo = fi.x, fa_hi = fi.y, fb_lo = fi.z, fb_hi = fi.w;
           for (int b = fb_lo; b <= fb_hi; ++b)
             for (int a = fa_lo; a <= fa_hi; ++a)
               if (zlo[2 * ((b - bb) * bw + (a - a_lo))] == (uint32_t)f) visit(f, a, b);
@@ -970,7 +982,7 @@ __device__ __forceinline__ void load_world_verts(const KParams &P, const Lds &L,
   const gf32p gv = as_global(M.verts);
   for (int i = threadIdx.x; i < M.F; i += NT)
     L.fc[i] = us4{(unsigned short)gf[3 * i], (unsigned short)gf[3 * i + 1], (unsigned short)gf[3 * i + 2], 0};
-  for (int i = threadIdx.x; i < P.S; i += NT) L.ndc[i] = ndc_of(i, (float)P.S);
+  for (int i = (int)threadIdx.x - 2; i < P.S + 2; i += NT) L.ndc[i] = ndc_of(i, (float)P.S);
   __syncthreads();
 }
 
@@ -1400,8 +1412,8 @@ static int plan_lds(nemo_ctx *ctx) {
   const nemo_config &c = ctx->cfg;
   const int vmax = ctx->vmax_seen > 0 ? ((ctx->vmax_seen + 63) & ~63) : 64;
   const int fmax = ctx->fmax_seen > 0 ? ((ctx->fmax_seen + 63) & ~63) : 64;
-  long avail = (long)LDS_BUDGET - (long)vmax * 16 - (long)fmax * 8 -
-               ((NW * RED_N + UST_N + c.raster_size + 4) * 4 + 128);
+  long avail = (long)LDS_BUDGET - (long)vmax * 16 - (long)fmax * 16 -
+               ((NW * RED_N + UST_N + c.raster_size + 12) * 4 + 128);
   long cap = avail / (8 + 4);
   if (cap > (long)c.win_h * c.win_w) cap = (long)c.win_h * c.win_w;
   if ((long)c.win_h * c.win_w > 65536)

@@ -113,3 +113,28 @@ def test_engine_fails_loudly_without_gpu():
         PoseEngine(40, (30, 40), 128)
     with pytest.raises(_lib.NemoHipError):
         PoseEngine(40, (30, 40), 128, device='cpu')
+
+
+def test_pixel_range_estimates_are_within_three_probes():
+    """The kernels settle 'first / last pixel centre inside [vmin, vmax]' with three probes of the
+    PixToNdc table around a closed-form estimate instead of a search loop (nemo_hip.hip, exact_range).
+    That is exact iff the float32 estimates floor(f), ceil(f), f = ((v + 1) * S - 1) / 2, are within
+    [0, +2] resp. [-2, 0] of the true indices: checked here over many raster sizes, including values
+    one ulp either side of every pixel centre."""
+    f32 = np.float32
+    rng = np.random.default_rng(0)
+    for S in [16, 30, 32, 48, 64, 75, 96, 100, 112, 125, 128, 160, 200, 224, 256, 333, 512, 1000]:
+        Sf = f32(S)
+        idx = np.arange(-4, S + 4)
+        ndc = (f32(-1.0) + (f32(2.0) * idx.astype(f32) + f32(1.0)) / Sf).astype(f32)  # PixToNdc
+        assert np.all(np.diff(ndc) > 0)
+        c = ndc[2:-2]
+        v = np.concatenate([rng.uniform(-1.0 - 1.5 / S, 1.0 + 1.5 / S, 200000).astype(f32), c,
+                            np.nextafter(c, f32(9)), np.nextafter(c, f32(-9))]).astype(f32)
+        f = ((np.clip(v, f32(-4), f32(4)) + f32(1.0)) * Sf - f32(1.0)) * f32(0.5)
+        assert f.dtype == np.float32
+        lo_true = np.searchsorted(ndc, v, side='left') - 4       # smallest i with ndc[i] >= v
+        hi_true = np.searchsorted(ndc, v, side='right') - 1 - 4  # largest i with ndc[i] <= v
+        dl, dh = lo_true - np.floor(f).astype(int), hi_true - np.ceil(f).astype(int)
+        assert dl.min() >= 0 and dl.max() <= 2, (S, dl.min(), dl.max())
+        assert dh.min() >= -2 and dh.max() <= 0, (S, dh.min(), dh.max())
