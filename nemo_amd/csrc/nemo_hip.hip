@@ -357,31 +357,38 @@ struct Lds {
   float *ust;            // [UST_N] workgroup-uniform state (camera, Adam)
 };
 
-// Score chunks come in guided sizes: CH entries for the bulk of the face-major list, then 64, then
-// 32 for the last NW*32 entries, so that the waves run out of work within a few pixels of each other.
+// Score chunks come in guided sizes: CH entries for the bulk of the face-major list, then CH_MID, then
+// CH_SMALL for the last NW*CH_SMALL entries, so that the waves run out of work within a few pixels of each other.
 // The plan is a function of the list length only (the chunk-order sum stays deterministic).
 struct ChunkPlan {
   int n_big, n_mid, b_mid, b_small, nchunks;
 };
-__host__ __device__ inline int max_chunks(int cap) { return cap / CH + 2 * NW + 8; }
+__host__ __device__ inline int max_chunks(int cap) { return cap / CH + 2 * NW + 24; }
+#ifndef NEMO_CHUNK_MID
+#define NEMO_CHUNK_MID 64
+#endif
+#ifndef NEMO_CHUNK_SMALL
+#define NEMO_CHUNK_SMALL 32
+#endif
+constexpr int CH_MID = NEMO_CHUNK_MID < CH ? NEMO_CHUNK_MID : CH, CH_SMALL = NEMO_CHUNK_SMALL;
 __device__ __forceinline__ ChunkPlan plan_chunks(int ntot) {
   ChunkPlan c;
-  const int bulk = max(0, ntot - NW * (32 + 64));
+  const int bulk = max(0, ntot - NW * (CH_SMALL + CH_MID));
   c.n_big = (bulk + CH - 1) / CH;
-  c.b_mid = c.n_big * CH;  // < ntot - NW*96 + CH
-  const int mid = max(0, ntot - c.b_mid - NW * 32);
-  c.n_mid = (mid + 63) / 64;
-  c.b_small = c.b_mid + c.n_mid * 64;
-  c.nchunks = c.n_big + c.n_mid + (max(0, ntot - c.b_small) + 31) / 32;
+  c.b_mid = c.n_big * CH;
+  const int mid = max(0, ntot - c.b_mid - NW * CH_SMALL);
+  c.n_mid = (mid + CH_MID - 1) / CH_MID;
+  c.b_small = c.b_mid + c.n_mid * CH_MID;
+  c.nchunks = c.n_big + c.n_mid + (max(0, ntot - c.b_small) + CH_SMALL - 1) / CH_SMALL;
   return c;
 }
 __device__ __forceinline__ void chunk_range(const ChunkPlan &c, int ntot, int id, int &cb, int &cn) {
   if (id < c.n_big) {
     cb = id * CH; cn = CH;
   } else if (id < c.n_big + c.n_mid) {
-    cb = c.b_mid + (id - c.n_big) * 64; cn = 64;
+    cb = c.b_mid + (id - c.n_big) * CH_MID; cn = CH_MID;
   } else {
-    cb = c.b_small + (id - c.n_big - c.n_mid) * 32; cn = 32;
+    cb = c.b_small + (id - c.n_big - c.n_mid) * CH_SMALL; cn = CH_SMALL;
   }
   cn = min(cn, ntot - cb);
 }
@@ -1419,7 +1426,7 @@ static int plan_lds(nemo_ctx *ctx) {
   if ((long)c.win_h * c.win_w > 65536)
     return fail(ctx, NEMO_ERR_UNSUPPORTED, "window %dx%d has more than 65536 pixels (16-bit pixel ids)", c.win_h, c.win_w);
   {  // the z-buffer region also hosts the chunk partials and the phase A->B hand-off buffer
-    const long fixed = (long)(NW * CH * (12 + 16) + 64 * (2 * NW + 8) + 192);
+    const long fixed = (long)(NW * CH * (12 + 16) + 64 * (2 * NW + 24) + 192);
     if (avail - fixed < cap * 4 + 64 * (cap / CH)) cap = (avail - fixed) / 5;
   }
   if (cap < c.win_w)
