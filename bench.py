@@ -64,6 +64,20 @@ def cpu_baseline(wl, n_sample):
                       f'one per host thread, {dt:.1f} s wall; host has {os.cpu_count()} logical CPUs'}
 
 
+def pmc_traffic(cov_steps):
+    """HBM bytes per launch of the solve kernel from the committed PMC passes (profiles/r01_pmc_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate runs of this workload, FETCH_SIZE doubled as the
+    gfx950 note in MI355X_MICROARCH.md prescribes), scaled by this launch's covered-pixel-steps.  bench.py
+    cannot collect counters itself; None if the file is missing."""
+    fn = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
+    try:
+        with open(fn) as f:
+            per = json.load(f)['solve_kernel']['hbm_bytes_per_covered_pixel_step']
+        return float(per) * float(cov_steps)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -162,7 +176,7 @@ def main():
                        'raster': eng.S, 'grid_poses': int(solver.grid_theta.shape[1]),
                        'adam_steps': solver.cfg.total_epochs, 'parallelism': f'images sharded over {world} GPU(s)'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'kernel': 'solve_kernel',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(cov_steps), 'kernel': 'solve_kernel',
                          'kernel_ms': solve_ms, 'algorithmic_bytes_per_launch': alg_bytes,
                          'covered_pixel_steps_per_launch': cov_steps},
             'quality': {'finite_fraction': ok, 'median_err_deg_vs_synthetic_gt': float(np.degrees(np.median(errs)))},
