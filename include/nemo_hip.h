@@ -146,6 +146,14 @@ int nemo_solve(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t
                const float *d_feat, const float *d_clu, const float *d_C0, const float *d_theta0,
                float *d_pose, float *d_loss, float *d_trace, void *stream);
 
+/* 6-DoF variant of the solve (code/PredUnlabeledDataset.py:318-347): Adam also moves trans_2d, which
+ * enters the camera as extra_trans = trans_2d @ [[1,0,0],[0,1,0]] added to T (:328, lib/MeshUtils.py:107-108).
+ * Same kernel as nemo_solve.  d_trans0 f32[N][2] (NULL = zeros, :318); d_pose6 f32[N][6] =
+ * (Cx,Cy,Cz,theta,t0,t1); d_trace f32[N][steps][13] = (p6, loss, g6) at the start of every step, or NULL. */
+int nemo_solve6(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t *d_mesh_idx,
+                const float *d_feat, const float *d_clu, const float *d_C0, const float *d_theta0,
+                const float *d_trans0, float *d_pose6, float *d_loss, float *d_trace, void *stream);
+
 /* Bytes the fused kernels read per covered pixel and step: 4*D + 4. */
 int64_t nemo_bytes_per_covered_pixel(const nemo_ctx *ctx);
 

@@ -45,6 +45,7 @@ constexpr int UST_N = 96;      // floats of workgroup-uniform state kept in LDS
 // uniform-state slots: R[0..8] T[9..11] p[12..15] m[16..19] v[20..23] K[24], chunk counter [25], block totals [32..45],
 // camera intermediates of the current iterate [48..82] (kept for the camera backward)
 constexpr int U_R = 0, U_T = 9, U_P = 12, U_M = 16, U_V = 20, U_K = 24, U_CTR = 25, U_TOT = 32, U_CAM = 48;
+constexpr int U_P6 = 84, U_M6 = 86, U_V6 = 88;  // 6-DoF variant: trans_2d and its Adam moments
 // block totals: [0] loss term, [1..9] dL/dR, [10..12] dL/dT, [13] covered pixels
 constexpr int T_LOSS = 0, T_GR = 1, T_GT = 10, T_NCOV = 13;
 constexpr int MAX_MESHES = 1024;
@@ -995,8 +996,9 @@ __device__ __forceinline__ void load_world_verts(const KParams &P, const Lds &L,
 
 // Thread-0 helpers working on the uniform state in LDS.
 static_assert(sizeof(Cam) == 35 * sizeof(float) && U_CAM + 35 <= UST_N, "camera slot");
-__device__ __forceinline__ void ust_set_camera(const Lds &L, const float *Cp, float theta, Cam &cam) {
-  dev_camera(Cp, theta, nullptr, cam);
+__device__ __forceinline__ void ust_set_camera(const Lds &L, const float *Cp, float theta, Cam &cam,
+                                               const float *extra = nullptr) {
+  dev_camera(Cp, theta, extra, cam);
 #pragma unroll
   for (int i = 0; i < 9; ++i) L.ust[U_R + i] = cam.R[i];
 #pragma unroll
@@ -1204,9 +1206,10 @@ __global__ void grid_argmin_kernel(int N, int G, const float *losses, const int3
 template <int D, bool PERSP>
 __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc *meshes, const int32_t *img_idx,
                                                       const int32_t *mesh_idx, const float *feat, const float *clu,
-                                                      const float *C0, const float *theta0, const float *adam_tab,
-                                                      int steps, float beta1, float beta2, float eps, float *pose,
-                                                      float *loss_out, float *trace, u64 *counter, int stagger) {
+                                                      const float *C0, const float *theta0, const float *trans0,
+                                                      int ndof, const float *adam_tab, int steps, float beta1,
+                                                      float beta2, float eps, float *pose, float *loss_out,
+                                                      float *trace, u64 *counter, int stagger) {
   const int n = blockIdx.x;
   const MeshDesc M = meshes[mesh_idx ? mesh_idx[n] : 0];
   const int img = img_idx ? img_idx[n] : n;
@@ -1229,8 +1232,13 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
     L.ust[U_P] = C0[3 * n]; L.ust[U_P + 1] = C0[3 * n + 1]; L.ust[U_P + 2] = C0[3 * n + 2]; L.ust[U_P + 3] = theta0[n];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { L.ust[U_M + i] = 0.f; L.ust[U_V + i] = 0.f; }
+    // 6-DoF (PredUnlabeledDataset.py:318-328): trans_2d enters as extra_trans = (t0, t1, 0) added to T
+    L.ust[U_P6] = (ndof == 6 && trans0) ? trans0[2 * n] : 0.f;
+    L.ust[U_P6 + 1] = (ndof == 6 && trans0) ? trans0[2 * n + 1] : 0.f;
+    L.ust[U_M6] = L.ust[U_M6 + 1] = L.ust[U_V6] = L.ust[U_V6 + 1] = 0.f;
+    const float ex[3] = {L.ust[U_P6], L.ust[U_P6 + 1], 0.f};
     Cam cam;
-    ust_set_camera(L, L.ust + U_P, L.ust[U_P + 3], cam);
+    ust_set_camera(L, L.ust + U_P, L.ust[U_P + 3], cam, ndof == 6 ? ex : nullptr);
   }
   __syncthreads();
   const float omb1 = (float)(1.0 - (double)beta1), omb2 = (float)(1.0 - (double)beta2);
@@ -1243,30 +1251,42 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
     const unsigned long long st_lead = (threadIdx.x == 0) ? __builtin_readcyclecounter() : 0ull;
 #endif
     if (lead) {
-      float p[4] = {L.ust[U_P], L.ust[U_P + 1], L.ust[U_P + 2], L.ust[U_P + 3]};
+      float p[6] = {L.ust[U_P], L.ust[U_P + 1], L.ust[U_P + 2], L.ust[U_P + 3], L.ust[U_P6], L.ust[U_P6 + 1]};
       Cam cam;
       ust_get_camera(L, cam);
-      float g[4];
+      float g[6];
       ust_totals_to_grad(L, cam, p, g);
+      g[4] = block_total(L, T_GT);      // dL/d extra_trans = dL/dT
+      g[5] = block_total(L, T_GT + 1);
       last_loss = L.ust[U_K] - P.inv_hw * block_total(L, 0);
       cov_total += (u64)(block_total(L, T_NCOV) + 0.5f);
       if (trace) {
-        float *tr = trace + ((size_t)n * steps + t) * 9;
-        tr[0] = p[0]; tr[1] = p[1]; tr[2] = p[2]; tr[3] = p[3]; tr[4] = last_loss;
-        tr[5] = g[0]; tr[6] = g[1]; tr[7] = g[2]; tr[8] = g[3];
+        if (ndof == 6) {
+          float *tr = trace + ((size_t)n * steps + t) * 13;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) { tr[i] = p[i]; tr[7 + i] = g[i]; }
+          tr[6] = last_loss;
+        } else {
+          float *tr = trace + ((size_t)n * steps + t) * 9;
+          tr[0] = p[0]; tr[1] = p[1]; tr[2] = p[2]; tr[3] = p[3]; tr[4] = last_loss;
+          tr[5] = g[0]; tr[6] = g[1]; tr[7] = g[2]; tr[8] = g[3];
+        }
       }
       // torch.optim.Adam (1.5.1 form) with the host-prepared per-step scalars
       const float step_size = adam_tab[2 * t], bc2s = adam_tab[2 * t + 1];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float m = L.ust[U_M + i], v = L.ust[U_V + i];
+      for (int i = 0; i < 6; ++i) {
+        if (i >= ndof) break;
+        const int um = i < 4 ? U_M + i : U_M6 + i - 4, uv = i < 4 ? U_V + i : U_V6 + i - 4, up = i < 4 ? U_P + i : U_P6 + i - 4;
+        float m = L.ust[um], v = L.ust[uv];
         m = m * beta1 + omb1 * g[i];
         v = v * beta2 + (omb2 * g[i]) * g[i];
         const float denom = sqrtf(v) / bc2s + eps;
         p[i] = p[i] - step_size * (m / denom);
-        L.ust[U_M + i] = m; L.ust[U_V + i] = v; L.ust[U_P + i] = p[i];
+        L.ust[um] = m; L.ust[uv] = v; L.ust[up] = p[i];
       }
-      ust_set_camera(L, p, p[3], cam);
+      const float ex[3] = {p[4], p[5], 0.f};
+      ust_set_camera(L, p, p[3], cam, ndof == 6 ? ex : nullptr);
     }
     __syncthreads();
 #ifdef NEMO_STAMPS
@@ -1277,8 +1297,9 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
 #endif
   }
   if (lead) {
-    pose[4 * n] = L.ust[U_P]; pose[4 * n + 1] = L.ust[U_P + 1]; pose[4 * n + 2] = L.ust[U_P + 2];
-    pose[4 * n + 3] = L.ust[U_P + 3];
+    float *po = pose + (size_t)ndof * n;
+    po[0] = L.ust[U_P]; po[1] = L.ust[U_P + 1]; po[2] = L.ust[U_P + 2]; po[3] = L.ust[U_P + 3];
+    if (ndof == 6) { po[4] = L.ust[U_P6]; po[5] = L.ust[U_P6 + 1]; }
     if (loss_out) loss_out[n] = last_loss;
     if (counter) atomicAdd(counter, cov_total);
   }
@@ -1688,8 +1709,25 @@ int nemo_solve(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t
   const char *stg = getenv("NEMO_SOLVE_STAGGER");
   const int stagger = stg ? atoi(stg) : 1;
   DISPATCH_DP(solve_kernel, dim3(N), ctx->P, ctx->d_meshes, d_img_idx, d_mesh_idx, d_feat, d_clu, d_C0, d_theta0,
-              ctx->d_adam, ctx->adam_steps, ctx->beta1, ctx->beta2, ctx->eps, d_pose, d_loss, d_trace, ctx->d_counter,
-              stagger);
+              (const float *)nullptr, 4, ctx->d_adam, ctx->adam_steps, ctx->beta1, ctx->beta2, ctx->eps, d_pose, d_loss,
+              d_trace, ctx->d_counter, stagger);
+  HIP_TRY(ctx, hipGetLastError());
+  return NEMO_OK;
+}
+
+int nemo_solve6(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t *d_mesh_idx, const float *d_feat,
+                const float *d_clu, const float *d_C0, const float *d_theta0, const float *d_trans0, float *d_pose6,
+                float *d_loss, float *d_trace, void *stream) {
+  int rc = check_ready(ctx, "nemo_solve6", N);
+  if (rc) return rc > 0 ? NEMO_OK : rc;
+  if (ctx->adam_steps <= 0) return fail(ctx, NEMO_ERR_STATE, "nemo_solve6: call nemo_set_schedule first");
+  if (!d_feat || !d_C0 || !d_theta0 || !d_pose6) return fail(ctx, NEMO_ERR_ARG, "nemo_solve6: null buffer");
+  if (ctx->cfg.clutter && !d_clu) return fail(ctx, NEMO_ERR_ARG, "nemo_solve6: clutter loss needs d_clu");
+  const char *stg = getenv("NEMO_SOLVE_STAGGER");
+  const int stagger = stg ? atoi(stg) : 1;
+  DISPATCH_DP(solve_kernel, dim3(N), ctx->P, ctx->d_meshes, d_img_idx, d_mesh_idx, d_feat, d_clu, d_C0, d_theta0,
+              d_trans0, 6, ctx->d_adam, ctx->adam_steps, ctx->beta1, ctx->beta2, ctx->eps, d_pose6, d_loss, d_trace,
+              ctx->d_counter, stagger);
   HIP_TRY(ctx, hipGetLastError());
   return NEMO_OK;
 }

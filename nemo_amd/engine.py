@@ -220,6 +220,19 @@ class PoseEngine:
             _ptr(loss), _ptr(trace), self._stream()), 'nemo_solve')
         return (pose, loss, trace) if want_trace else (pose, loss)
 
+    def solve6(self, feat, clu, C0, theta0, trans0=None, img_idx=None, mesh_idx=None, want_trace=False):
+        """6-DoF solve (code/PredUnlabeledDataset.py:318-347): returns pose6 [N,6] = (C, theta, trans_2d), loss
+        (and the [N,steps,13] trace)."""
+        C0, theta0 = self._f32(C0, 'C0'), self._f32(theta0, 'theta0')
+        N = C0.shape[0]
+        pose, loss = self._empty((N, 6)), self._empty((N,))
+        trace = self._empty((N, self.steps, 13)) if want_trace else None
+        _lib.check(self.ctx, self.lib.nemo_solve6(
+            self.ctx, N, _ptr(self._i32(img_idx, 'img_idx')), _ptr(self._i32(mesh_idx, 'mesh_idx')),
+            _ptr(self._f32(feat, 'feat')), _ptr(self._f32(clu, 'clu')), _ptr(C0), _ptr(theta0),
+            _ptr(self._f32(trans0, 'trans0')), _ptr(pose), _ptr(loss), _ptr(trace), self._stream()), 'nemo_solve6')
+        return (pose, loss, trace) if want_trace else (pose, loss)
+
     # ------------------------------------------------------------------ accounting
     def bytes_per_covered_pixel(self) -> int:
         return int(self.lib.nemo_bytes_per_covered_pixel(self.ctx))

@@ -83,6 +83,19 @@ class SolverConfig:
     turn_off_clutter: bool = False
     perspective_correct: bool = False
     k_eps: float = 1e-8
+    # 6-DoF variant (code/PredUnlabeledDataset.py:283-347): Adam also moves the 2-D translation; the grid
+    # samples three distances and theta = 0
+    six_dof: bool = False
+    grid_distances: Optional[Sequence[float]] = None
+    grid_thetas: Optional[Sequence[float]] = None
+
+    @staticmethod
+    def unlabeled_6dof(**kw) -> 'SolverConfig':
+        """The settings of code/PredUnlabeledDataset.py:283-286 (cars: image 256x672 in that script)."""
+        kw.setdefault('six_dof', True)
+        kw.setdefault('grid_distances', (4.4, 5.0, 5.7))
+        kw.setdefault('grid_thetas', (0.0,))
+        return SolverConfig(**kw)
 
 
 @dataclass
@@ -95,6 +108,13 @@ class SolveResult:
     campos: torch.Tensor
     init_index: torch.Tensor
     trace: Optional[torch.Tensor] = None
+    trans_2d: Optional[torch.Tensor] = None   # [N,2], 6-DoF variant only
+
+    def preds6(self) -> torch.Tensor:
+        """[N,6] rows of final_pred.npz (code/PredUnlabeledDataset.py:344-347, README.md:96):
+        distance, theta, elevation, azimuth, trans_2d (2)."""
+        t = self.trans_2d if self.trans_2d is not None else torch.zeros_like(self.campos[:, :2])
+        return torch.cat([torch.stack([self.distance, self.theta, self.elevation, self.azimuth], dim=1), t], dim=1)
 
     def packed(self) -> torch.Tensor:
         """[N, 8] f32 record gathered across ranks: dist, elev, azim, theta, loss, init, status, pad."""
@@ -128,7 +148,8 @@ class BatchPoseSolver:
         v = np.asarray(verts_pascal, dtype=np.float32)
         vp = np.stack([v[:, 0], v[:, 2], -v[:, 1]], 1)  # pre_process_mesh_pascal, lib/MeshUtils.py:115-117
         mid = self.engine.register_mesh(vp, faces, memory_bank)
-        gC, gt = syn.pose_grid(distance, self.cfg.n_azimuth, self.cfg.n_elevation, self.cfg.n_theta, distances)
+        gC, gt = syn.pose_grid(distance, self.cfg.n_azimuth, self.cfg.n_elevation, self.cfg.n_theta,
+                               distances if distances is not None else self.cfg.grid_distances, self.cfg.grid_thetas)
         self._grids_C.append(gC)
         self._grids_t.append(gt)
         self.grid_C = torch.as_tensor(np.stack(self._grids_C)).to(self.device).contiguous()
@@ -157,11 +178,15 @@ class BatchPoseSolver:
         self.prerender()
         C0, th0, best, _ = eng.grid_search(feats, clu, self.grid_C, self.grid_theta, n_jobs=n_jobs,
                                            img_idx=img_idx, mesh_idx=mesh_idx, grid_idx=mesh_idx)
-        out = eng.solve(feats, clu, C0, th0, img_idx=img_idx, mesh_idx=mesh_idx, want_trace=want_trace)
+        if self.cfg.six_dof:
+            out = eng.solve6(feats, clu, C0, th0, None, img_idx=img_idx, mesh_idx=mesh_idx, want_trace=want_trace)
+        else:
+            out = eng.solve(feats, clu, C0, th0, img_idx=img_idx, mesh_idx=mesh_idx, want_trace=want_trace)
         pose, loss = out[0], out[1]
         campos = pose[:, :3]
         dist, elev, azim = camera_position_to_spherical_angle(campos)
-        return SolveResult(pose[:, 3], dist, elev, azim, loss, campos, best, out[2] if want_trace else None)
+        return SolveResult(pose[:, 3], dist, elev, azim, loss, campos, best, out[2] if want_trace else None,
+                           pose[:, 4:6].contiguous() if self.cfg.six_dof else None)
 
 
 def features_to_pixel_major(predicted_map: torch.Tensor) -> torch.Tensor:

@@ -115,13 +115,13 @@ def spherical_to_campos(dist, elev, azim):
     return np.stack(np.broadcast_arrays(x, y, z), -1).astype(np.float32)
 
 
-def pose_grid(distance, n_azim=12, n_elev=4, n_theta=3, distances=None):
+def pose_grid(distance, n_azim=12, n_elev=4, n_theta=3, distances=None, thetas=None):
     """The reference's init grid (code/MeshPoseSolveAll.py:193-195, :66): azimuth-major,
-    then elevation, then theta; optional innermost distance axis
-    (PredUnlabeledDataset.py:153-154)."""
+    then elevation, then theta; optional innermost distance axis and explicit theta samples
+    (PredUnlabeledDataset.py:153-154, :283-286: theta_sample = [0], dist_sample = [4.4, 5, 5.7])."""
     az = np.linspace(0, np.pi * 2, n_azim, endpoint=False)
     el = np.linspace(-np.pi / 6, np.pi / 3, n_elev)
-    th = np.linspace(-np.pi / 6, np.pi / 6, n_theta)
+    th = np.linspace(-np.pi / 6, np.pi / 6, n_theta) if thetas is None else np.asarray(thetas, dtype=np.float64)
     ds = [distance] if distances is None else list(distances)
     samples = [(a, e, t, d) for a in az for e in el for t in th for d in ds]
     s = np.asarray(samples, dtype=np.float64)

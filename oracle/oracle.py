@@ -163,6 +163,23 @@ def grid_search(cfg, verts, faces, bank, feat, clu, gridC, grid_theta):
     return int(best), losses
 
 
+def solve6(cfg, verts, faces, bank, feat, clu, C0, theta0, adam_tab, trans0=None, b1=0.4, b2=0.6, eps=1e-8,
+           want_trace=False):
+    """6-DoF solve (PredUnlabeledDataset.py:318-339): returns p6 = (C, theta, t0, t1), loss, trace [steps,13]."""
+    verts, faces, bank, feat = _f(verts), _i(faces), _f(bank), _f(feat)
+    clu = _f(clu) if clu is not None else None
+    adam_tab = _f(adam_tab)
+    steps = len(adam_tab)
+    out_p, ol = np.zeros(6, np.float32), C.c_float()
+    trace = np.zeros((steps, 13), np.float32) if want_trace else None
+    t0 = _f(trans0).reshape(2) if trans0 is not None else None
+    lib().orc_solve6(C.byref(cfg), _p(verts), C.c_int(len(verts)), _p(faces), C.c_int(len(faces)),
+                     _p(bank), _p(feat), _p(clu), _p(_f(C0).reshape(3)), C.c_float(float(theta0)), _p(t0),
+                     C.c_int(steps), C.c_float(b1), C.c_float(b2), C.c_float(eps), _p(adam_tab),
+                     _p(out_p), C.byref(ol), _p(trace))
+    return out_p, ol.value, trace
+
+
 def solve_batch(cfg, verts, faces, bank, feats, cvec, gridC, grid_theta, adam_tab, b1=0.4, b2=0.6,
                 eps=1e-8, nthreads=0):
     """clutter score + grid init + full solve for N images (OpenMP over images)."""

@@ -241,6 +241,49 @@ def test_solve_teacher_forced_and_final_pose(oracle, persp):
         assert np.degrees(pose_error(_decode(pose[i, :3], pose[i, 3]), (th_gt, el, az, d))) < 5.0
 
 
+def test_solve6_teacher_forced_and_final_pose(oracle):
+    """6-DoF variant (code/PredUnlabeledDataset.py:283-347): three-distance / theta=0 grid, Adam on
+    (C, theta, trans_2d) with extra_trans = (t0, t1, 0).  Teacher-forced parity of loss and all six
+    gradient components along the GPU's trajectory, the Adam update itself, and the final pose."""
+    sc = make_scene(n_img=3)
+    eng = _engine(sc)
+    tab = eng.set_schedule(300)
+    gC, gth = syn.pose_grid(sc.distance, distances=(0.88 * sc.distance, sc.distance, 1.14 * sc.distance), thetas=(0.0,))
+    assert len(gth) == 144
+    feats, clus = _dev(sc.feats), _dev(sc.clus)
+    C0, th0, best, _ = eng.grid_search(feats, clus, _dev(gC[None]), _dev(gth[None]))
+    pose6, loss, trace = eng.solve6(feats, clus, C0, th0, None, want_trace=True)
+    pose6, trace = pose6.cpu().numpy(), trace.cpu().numpy()
+    assert np.isfinite(pose6).all() and trace.shape == (3, 300, 13)
+    n_checked = 0
+    for i in range(3):
+        assert np.all(trace[i, 0, 4:6] == 0.0)  # trans_2d starts at zero (:318)
+        for t in list(range(0, 300, 29)) + [299]:
+            p = trace[i, t, 0:6]
+            e = oracle.evaluate(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[i], sc.clus[i], p[0:3], p[3],
+                                extra=np.array([p[4], p[5], 0.0], np.float32))
+            assert abs(trace[i, t, 6] - e['loss']) <= REL * abs(e['loss'])
+            assert _relerr(trace[i, t, 7:13], np.r_[e['gC'], e['gtheta'], e['gextra'][:2]]) <= REL
+        # the Adam update between two recorded iterates, replayed by the oracle on the GPU's own gradients
+        m, v = np.zeros(6, np.float32), np.zeros(6, np.float32)
+        p = trace[i, 0, 0:6].copy()
+        for t in range(5):
+            p, m, v = oracle.adam_step(p, m, v, trace[i, t, 7:13], 0.4, 0.6, tab[t, 0], tab[t, 1])
+            assert np.array_equal(p, trace[i, t + 1, 0:6]), (i, t)
+        # free-running oracle from the same start.  Adam moves trans_2d by up to lr = 0.05 object units per
+        # step, which on this 32x48 map makes some trajectories chaotic (the oracle itself then ends far from
+        # the ground truth); the final-pose comparison is made where the oracle's own solve is well behaved.
+        b = int(best[i])
+        op, _, _ = oracle.solve6(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[i], sc.clus[i], gC[b], gth[b], tab)
+        az, el, th_gt, d = sc.gt[i]
+        if np.degrees(pose_error(_decode(op[:3], op[3]), (th_gt, el, az, d))) < 2.0 and np.abs(op[4:6]).max() < 0.05:
+            n_checked += 1
+            err = pose_error(_decode(pose6[i, :3], pose6[i, 3]), _decode(op[:3], op[3]))
+            assert np.degrees(err) <= 0.5, (i, np.degrees(err))
+            assert np.abs(pose6[i, 4:6] - op[4:6]).max() <= 5e-3
+    assert n_checked >= 1
+
+
 def test_interpolate_backward_matches_score_gradient(oracle):
     """dL/dR, dL/dT from the module-path backward, chained on the host, equal the fused gradient."""
     from oracle import torch_ref

@@ -146,3 +146,25 @@ def test_solve_recovers_synthetic_pose(oracle):
     dist = np.sqrt((C ** 2).sum()); azim = np.arctan(C[0] / C[2]) % np.pi + np.pi * (C[0] < 0); elev = np.arcsin(C[1] / dist)
     az, el, th, d = g['gt']
     assert np.degrees(pose_error((float(g['final_theta']), elev, azim, dist), (th, el, az, d))) < 3.0
+
+
+def test_solve6_oracle_gradients_and_descent():
+    """6-DoF restatement (code/PredUnlabeledDataset.py:318-339): the gradient w.r.t. trans_2d is dL/dT's first
+    two components (checked against torch autograd through extra_trans), and with trans_2d frozen at zero
+    gradient weight the first iterate equals the 4-DoF one."""
+    from oracle import oracle as orc, torch_ref
+    sc = make_scene(cate='car', image_hw=(128, 192), number_vertices=150, n_img=1, seed=5)
+    az, el, th, d = sc.gt[0]
+    C0 = syn.spherical_to_campos(d * 1.04, el + 0.05, az - 0.06)
+    ex = np.array([0.03, -0.02, 0.0], np.float32)
+    e = orc.evaluate(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[0], sc.clus[0], C0, th + 0.02, extra=ex, want_maps=True)
+    a = torch_ref.loss_and_grads(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[0], sc.clus[0], C0, th + 0.02,
+                                 e['pix_to_face'].reshape(sc.cfg.h, sc.cfg.w), extra=ex)
+    assert abs(e['loss'] - a['loss']) < 1e-5
+    assert np.abs(e['gextra'] - a['gextra']).max() <= 1e-4 * max(1e-3, np.abs(a['gextra']).max())
+    tab = syn.adam_table(40)
+    p6, l6, tr6 = orc.solve6(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[0], sc.clus[0], C0, th + 0.02, tab, want_trace=True)
+    _, _, _, tr4 = orc.solve(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[0], sc.clus[0], C0, th + 0.02, tab, want_trace=True)
+    assert np.array_equal(tr6[0, 0:4], tr4[0, 0:4]) and tr6[0, 6] == tr4[0, 4]
+    assert np.array_equal(tr6[0, 7:11], tr4[0, 5:9])          # same first gradient in (C, theta)
+    assert tr6[-1, 6] < tr6[0, 6]                               # it descends
