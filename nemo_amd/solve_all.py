@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Batched stand-in for `python code/MeshPoseSolveAll.py` (one category per call).
+
+Same flags where they mean the same thing (code/MeshPoseSolveAll.py:8-28), same inputs (the feature .npz
+of ExtractFeatures.py, the category's CAD .off meshes, per-image annotation .npz) and the same outputs
+(`--save_accuracy` record for CalAccuracy.py, or the Thr / Med lines on stdout, :273-287).  The per-image
+Python loop (:217-271) is replaced by clutter score -> pre-rendered grid search -> fused solve over all
+images of the category at once; under `python -m torch.distributed.run` the images are sharded over ranks
+and the error lists gathered on rank 0 (InferenceNeMo.sh's per-category processes + file merge).
+
+`python -m nemo_amd.solve_all --accuracy_table DIR` is code/CalAccuracy.py.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import records
+from . import synthetic as syn
+from .mesh_utils import load_off
+from .pose_solver import BatchPoseSolver, SolverConfig
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description='NeMo pose estimation (MI355X batched path)')
+    p.add_argument('--type_', default='car', type=str)
+    p.add_argument('--mesh_d', default='build', type=str)
+    p.add_argument('--turn_off_clutter', default=False, type=lambda s: str(s).lower() in ('1', 'true', 'yes'))
+    p.add_argument('--data_pendix', default='', type=str)
+    p.add_argument('--feature_path', default='saved_features', type=str)
+    p.add_argument('--feature_name', default='3D512_points1saved_model_%s_799.pth', type=str)
+    p.add_argument('--record_file', default='', type=str, help='explicit feature .npz (overrides feature_path/name)')
+    p.add_argument('--save_accuracy', default='', type=str)
+    p.add_argument('--mesh_path', default='../PASCAL3D/PASCAL3D+_release1.1/CAD_%s/%s/', type=str)
+    p.add_argument('--anno_path', default='../data/PASCAL3D_NeMo/annotations/%s/', type=str)
+    p.add_argument('--total_epochs', default=300, type=int)
+    p.add_argument('--lr', default=5e-2, type=float)
+    p.add_argument('--adam_beta_0', default=0.4, type=float)
+    p.add_argument('--adam_beta_1', default=0.6, type=float)
+    p.add_argument('--image_size', default='', type=str, help='H,W override of the category table (:142-145)')
+    p.add_argument('--feat_dim', default=128, type=int)
+    p.add_argument('--six_dof', action='store_true', help='PredUnlabeledDataset.py variant; writes --save_final_pred')
+    p.add_argument('--save_final_pred', default='', type=str)
+    p.add_argument('--accuracy_table', default='', type=str, help='directory of per-category records: print CalAccuracy table')
+    return p
+
+
+def record_path(args):
+    """code/MeshPoseSolveAll.py:156-167."""
+    if args.record_file:
+        return args.record_file
+    name = args.feature_name % (args.type_, args.mesh_d) if args.feature_name.count('%s') == 2 else args.feature_name
+    if len(args.data_pendix) > 0:
+        return os.path.join(args.feature_path, args.type_ + '_occ', args.data_pendix + '_' + name)
+    return os.path.join(args.feature_path, args.type_, name)
+
+
+def solve_category(args, device='cuda:0', rank=0, world=1):
+    cate = args.type_
+    image_size = tuple(int(v) for v in args.image_size.split(',')) if args.image_size else syn.IMAGE_SIZES[cate]
+    mesh_dir = args.mesh_path % (args.mesh_d, cate) if args.mesh_path.count('%s') == 2 else args.mesh_path
+    anno_dir = args.anno_path % cate if '%s' in args.anno_path else args.anno_path
+    kw = dict(image_size=image_size, feat_dim=args.feat_dim, total_epochs=args.total_epochs, lr=args.lr,
+              adam_beta_0=args.adam_beta_0, adam_beta_1=args.adam_beta_1, turn_off_clutter=args.turn_off_clutter)
+    cfg = SolverConfig.unlabeled_6dof(**kw) if args.six_dof else SolverConfig(**kw)
+    solver = BatchPoseSolver(cfg, device)
+    n_mesh = len([f for f in os.listdir(mesh_dir) if f.endswith('.off')])
+    subtypes = ['mesh%02d' % i for i in range(1, 1 + n_mesh)]                      # :172
+    with records.FeatureRecord(record_path(args)) as rec:
+        names, mesh_of = [], []
+        clutter = None
+        for k, st in enumerate(subtypes):                                          # :199-207
+            xvert, xface = load_off(os.path.join(mesh_dir, '%02d.off' % (k + 1)))
+            solver.add_mesh(xvert, xface, rec.memory(st), syn.DISTANCE_RENDER[cate])
+            if clutter is None:
+                clutter = solver.clutter_vector(torch.from_numpy(rec.clutter(st)).to(solver.device))
+            for n in rec.names(st):
+                names.append(n)
+                mesh_of.append(k)
+        lo, hi = (len(names) * rank) // world, (len(names) * (rank + 1)) // world  # contiguous image shard
+        my_names, my_mesh = names[lo:hi], mesh_of[lo:hi]
+        feats = rec.upload_pixel_major(my_names, solver.device) if my_names else None
+    if not my_names:
+        return [], [], np.zeros((0, 6), np.float32)
+    mesh_idx = torch.tensor(my_mesh, dtype=torch.int32, device=solver.device)
+    res = solver.solve_all(feats, clutter, mesh_idx)
+    theta, dist, elev, azim = (t.cpu().numpy() for t in (res.theta, res.distance, res.elevation, res.azimuth))
+    errors, cads = [], []
+    if anno_dir and os.path.isdir(anno_dir):
+        for i, n in enumerate(my_names):                                           # :256-271
+            a = records.load_annotation(os.path.join(anno_dir, n + '.npz'))
+            errors.append(records.rotation_error(a, theta[i], elev[i], azim[i], dist[i]))
+            cads.append(a.cad_index)
+    return my_names, list(zip(errors, cads)), res.preds6().cpu().numpy()
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.accuracy_table:
+        _, text = records.accuracy_table_from_dir(args.accuracy_table, args.data_pendix)
+        print(text)
+        return 0
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl' if torch.cuda.is_available() else 'gloo')
+    names, errs, preds = solve_category(args, 'cuda:%d' % local, rank, world)
+    if world > 1:
+        import torch.distributed as dist
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (names, errs, preds))
+        names = [n for g in gathered for n in g[0]]
+        errs = [e for g in gathered for e in g[1]]
+        preds = np.concatenate([g[2] for g in gathered], 0)
+        dist.destroy_process_group()
+    if rank != 0:
+        return 0
+    if args.save_final_pred:                                                       # PredUnlabeledDataset.py:344-352
+        os.makedirs(os.path.dirname(os.path.abspath(args.save_final_pred)), exist_ok=True)
+        np.savez(args.save_final_pred, **{n: preds[i] for i, n in enumerate(names)})
+    total_error = [e for e, _ in errs]
+    if args.save_accuracy:                                                         # :273-274
+        records.save_category_errors(args.save_accuracy, total_error, [c for _, c in errs])
+    elif total_error:                                                              # :275-287
+        te = np.asarray(total_error)
+        for thr in (np.pi / 6, np.pi / 18):
+            print('Thr: ', thr)
+            print('Average\t%d\t%.3f' % (len(te), float(np.mean(te < thr))))
+        print('Med')
+        print('Average\t%d\t%.3f' % (len(te), float(180 / np.pi * np.median(te))))
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

@@ -5,6 +5,7 @@ PyTorch3D cannot run here): the oracle is the build's own CPU restatement.
 Bars (BASELINE.json north_star): pix_to_face bit-exact; per-step loss and camera
 gradients within 1e-4 relative; final poses within 0.5 degrees.
 """
+import os
 import numpy as np
 import pytest
 
@@ -485,3 +486,43 @@ def test_reference_style_loop_through_module(oracle):
         optim.step()
         optim.zero_grad()
     assert np.abs(np.r_[C.detach().cpu().numpy()[0], theta.item()] - trace[6, :4]).max() < 5e-3
+
+
+def test_solve_all_runner_from_files(tmp_path):
+    """`python -m nemo_amd.solve_all` (the batched code/MeshPoseSolveAll.py): feature npz + CAD .off files +
+    per-image annotation npz in, per-category error record out, then the CalAccuracy table."""
+    from nemo_amd import mesh_utils as mu, records, solve_all
+    image_hw = (256, 384)
+    scs = [make_scene(image_hw=image_hw, n_img=3, seed=21), make_scene(image_hw=image_hw, n_img=2, seed=22,
+                                                                          jitter=np.array([1.1, 0.9, 1.05]))]
+    mesh_dir, anno_dir = tmp_path / 'CAD_build' / 'car', tmp_path / 'annotations' / 'car'
+    os.makedirs(mesh_dir); os.makedirs(anno_dir)
+    mem, clu, names, feats = {}, {}, {}, {}
+    for k, sc in enumerate(scs):
+        st = 'mesh%02d' % (k + 1)
+        pascal = np.stack([sc.verts[:, 0], -sc.verts[:, 2], sc.verts[:, 1]], 1)       # undo pre_process_mesh_pascal
+        mu.save_off(str(mesh_dir / ('%02d.off' % (k + 1))), pascal, sc.faces)
+        mem[st] = sc.bank
+        clu[st] = np.repeat(scs[0].cvec[None], 5, 0)                                   # mean -> the clutter vector
+        names[st] = ['img_%d_%d' % (k, i) for i in range(len(sc.feats))]
+        for i, n in enumerate(names[st]):
+            feats[n] = np.ascontiguousarray(sc.feats[i].transpose(2, 0, 1))            # [D,h,w] as ExtractFeatures
+            az, el, th, d = sc.gt[i]
+            records.write_annotation(str(anno_dir / (n + '.npz')), records.Annotation(th, el, az, d, k + 1))
+    rec_path = str(tmp_path / 'saved_features' / 'car' / 'rec.npz')
+    records.write_feature_record(rec_path, mem, clu, names, feats)
+    acc_path = str(tmp_path / 'acc' / 'car.npz')
+    rc = solve_all.main(['--type_', 'car', '--record_file', rec_path, '--mesh_path', str(mesh_dir),
+                         '--anno_path', str(anno_dir), '--save_accuracy', acc_path, '--image_size', '256,384'])
+    assert rc == 0
+    te = records.load_category_errors(acc_path)
+    assert te.shape == (5,) and np.all(np.isfinite(te))
+    assert np.degrees(np.median(te)) < 2.0 and np.mean(te < np.pi / 18) >= 0.8
+    rows, text = records.accuracy_table_from_dir(str(tmp_path / 'acc'), categories=['car'])
+    assert rows[3, 0] == 5 and 'MedErr' in text
+    # 6-DoF variant through the same runner: final_pred.npz rows (PredUnlabeledDataset.py:344-347)
+    pred_path = str(tmp_path / 'final_pred.npz')
+    assert solve_all.main(['--type_', 'car', '--record_file', rec_path, '--mesh_path', str(mesh_dir), '--anno_path', '',
+                           '--image_size', '256,384', '--six_dof', '--save_final_pred', pred_path]) == 0
+    with np.load(pred_path) as z:
+        assert sorted(z.files) == sorted(feats) and all(z[n].shape == (6,) and np.all(np.isfinite(z[n])) for n in z.files)

@@ -138,3 +138,59 @@ def test_pixel_range_estimates_are_within_three_probes():
         dl, dh = lo_true - np.floor(f).astype(int), hi_true - np.ceil(f).astype(int)
         assert dl.min() >= 0 and dl.max() <= 2, (S, dl.min(), dl.max())
         assert dh.min() >= -2 and dh.max() <= 0, (S, dh.min(), dh.max())
+
+
+def test_feature_record_round_trip_and_upload(tmp_path):
+    """ExtractFeatures.py npz format (:137-139,166-168,223): writer -> lazy reader -> pixel-major batch."""
+    import torch
+    from nemo_amd import records
+    rng = np.random.default_rng(3)
+    D, h, w = 8, 5, 6
+    names = {'mesh01': ['n02814533_1', 'n02814533_2'], 'mesh02': ['n03770679_9']}
+    feats = {n: rng.normal(size=(D, h, w)).astype(np.float32) for st in names for n in names[st]}
+    mem = {st: rng.normal(size=(7, D)).astype(np.float32) for st in names}
+    clu = {st: rng.normal(size=(11, D)).astype(np.float32) for st in names}
+    path = str(tmp_path / 'car' / 'rec.npz')
+    records.write_feature_record(path, mem, clu, names, feats)
+    with records.FeatureRecord(path) as rec:
+        assert rec.subtypes == ['mesh01', 'mesh02']
+        assert rec.names('mesh01') == names['mesh01'] and sorted(rec.image_keys) == sorted(feats)
+        assert np.array_equal(rec.memory('mesh02'), mem['mesh02']) and np.array_equal(rec.clutter('mesh01'), clu['mesh01'])
+        order = names['mesh02'] + names['mesh01']
+        batch = rec.upload_pixel_major(order, 'cpu', chunk=2)
+    assert batch.shape == (3, h, w, D) and batch.is_contiguous()
+    for i, n in enumerate(order):
+        assert torch.equal(batch[i], torch.from_numpy(feats[n]).permute(1, 2, 0))
+
+
+def test_accuracy_table_matches_cal_accuracy_arithmetic(tmp_path):
+    """code/CalAccuracy.py:15-44 on per-category error records written by save_category_errors."""
+    from nemo_amd import records
+    rng = np.random.default_rng(4)
+    errs = {}
+    for i, c in enumerate(records.CATEGORIES):
+        e = np.abs(rng.normal(scale=0.3, size=20 + 3 * i))
+        errs[c] = e
+        records.save_category_errors(str(tmp_path / ('%s.npz' % c)), e, cad_index=np.ones(e.size, int))
+    rows, text = records.accuracy_table_from_dir(str(tmp_path))
+    n = np.array([errs[c].size for c in records.CATEGORIES], float)
+    pi6 = np.array([np.mean(errs[c] < np.pi / 6) * 100 for c in records.CATEGORIES])
+    med = np.array([np.degrees(np.median(errs[c])) for c in records.CATEGORIES])
+    assert np.allclose(rows[0, :-1], pi6) and np.allclose(rows[2, :-1], med) and np.allclose(rows[3, :-1], n)
+    assert np.isclose(rows[0, -1], (n * pi6).sum() / n.sum()) and np.isclose(rows[2, -1], (n * med).sum() / n.sum())
+    lines = text.split('\n')
+    assert lines[0].startswith('Metric | plane\tbike\t') and lines[0].endswith('tv\tMean')
+    assert lines[1].startswith('Pi/6   | ') and lines[2].startswith('Pi/18  | ') and lines[3].startswith('MedErr | ')
+    assert lines[1].split('\t')[-1] == '%.1f' % rows[0, -1]
+
+
+def test_annotation_round_trip_and_rotation_error(tmp_path):
+    from nemo_amd import records
+    a = records.Annotation(theta=0.1, elevation=0.2, azimuth=1.3, distance=5.0, cad_index=2)
+    p = str(tmp_path / 'anno' / 'img.npz')
+    records.write_annotation(p, a)
+    b = records.load_annotation(p)
+    assert b == a
+    assert records.rotation_error(a, 0.1, 0.2, 1.3, 5.0) < 1e-6
+    assert abs(records.rotation_error(a, 0.1 + 0.05, 0.2, 1.3, 5.0) - 0.05) < 1e-6   # in-plane rotation only
+    assert records.rotation_error(a, float('nan'), 0.2, 1.3, 5.0) == np.pi / 2          # :262-263
