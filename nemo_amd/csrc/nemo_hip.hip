@@ -1130,7 +1130,7 @@ __global__ __launch_bounds__(NT, 4) void grid_kernel(KParams P, const MeshDesc *
                                                      const int32_t *mesh_idx, const int32_t *grid_idx,
                                                      const float *feat, const float *clu, const float *gridC,
                                                      const float *gridTheta, int G, float *losses, u64 *counter,
-                                                     PreStore pre) {
+                                                     PreStore pre, int skip_prepared) {
   const int GB = (G + GRID_POSES_PER_WG - 1) / GRID_POSES_PER_WG;
   const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
   const int n = (k / GB) * 8 + xcd, g0 = (k % GB) * GRID_POSES_PER_WG;
@@ -1140,6 +1140,7 @@ __global__ __launch_bounds__(NT, 4) void grid_kernel(KParams P, const MeshDesc *
   const int img = img_idx ? img_idx[n] : n;
   const int gi = grid_idx ? grid_idx[n] : 0;
   const int slot = (pre.slot && gi < MAX_GRIDS) ? pre.slot[mi * MAX_GRIDS + gi] : -1;
+  if (skip_prepared && slot >= 0) return;  // handled by the MFMA path over the pre-rendered maps
   const size_t hw = (size_t)P.h * P.w;
   const float *f = feat + (size_t)img * hw * D;
   const float *c = clu ? clu + (size_t)img * hw : nullptr;
@@ -1172,6 +1173,176 @@ __global__ __launch_bounds__(NT, 4) void grid_kernel(KParams P, const MeshDesc *
     }
   }
   if (threadIdx.x == 0 && counter) atomicAdd(counter, ncov_sum);
+}
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+// ---------------------------------------------------------------- grid search on the matrix cores
+// get_init_pos_rendered (code/MeshPoseSolveAll.py:84-100) compares an image with the stored renders of all
+// grid poses: object_score[g, p] = sum_d render[g, p, d] * feature[p, d].  With the renders of a (mesh, grid)
+// pair kept as dense pixel-major maps (nemo_grid_prerender) that is, per pixel, a small GEMM
+//   [jobs of the pair] x D  times  D x [G poses]
+// whose operands are read once.  A workgroup owns (pair, chunk of GP_PIX pixels); wave w owns the 32 poses
+// 32w..32w+31 and walks the pair's jobs 32*GP_TILES at a time with v_mfma_f32_32x32x2_f32 (exact fp32 FMA
+// chains); the loss terms max(obj, clu) - max(0, clu) are summed over the chunk's pixels in registers and
+// left as per-chunk partials, which grid_finish_kernel adds in chunk order (deterministic).
+constexpr int GP_PIX = 64;
+#ifndef NEMO_GP_TILES
+#define NEMO_GP_TILES 2
+#endif
+constexpr int GP_TILES = NEMO_GP_TILES;
+constexpr int GP_MAX_PAIRS = 2048;
+
+__global__ void gather_pose_kernel(int n, const int32_t *gidx, const float *gridC, const float *gridTheta, float *C, float *theta) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int g = gidx[k];
+  C[3 * k] = gridC[3 * g]; C[3 * k + 1] = gridC[3 * g + 1]; C[3 * k + 2] = gridC[3 * g + 2];
+  theta[k] = gridTheta[g];
+}
+
+// Jobs grouped by pre-render slot: order[] lists the job ids slot by slot, slot_start[] the ranges,
+// job_slot[n] the slot of job n (-1: not pre-rendered, evaluated on the fly by grid_kernel).
+__global__ __launch_bounds__(1024) void grid_group_kernel(int N, const int32_t *mesh_idx, const int32_t *grid_idx,
+                                                          const int32_t *slot_tab, int n_pairs, int32_t *order,
+                                                          int32_t *slot_start, int32_t *job_slot) {
+  __shared__ int cnt[GP_MAX_PAIRS + 1];
+  for (int i = threadIdx.x; i <= n_pairs; i += blockDim.x) cnt[i] = 0;
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    const int mi = mesh_idx ? mesh_idx[n] : 0, gi = grid_idx ? grid_idx[n] : 0;
+    const int sl = gi < MAX_GRIDS ? slot_tab[mi * MAX_GRIDS + gi] : -1;
+    job_slot[n] = sl;
+    if (sl >= 0) atomicAdd(&cnt[sl], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int i = 0; i < n_pairs; ++i) {
+      const int c = cnt[i];
+      slot_start[i] = run;
+      cnt[i] = run;  // becomes the placement cursor
+      run += c;
+    }
+    slot_start[n_pairs] = run;
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    const int sl = job_slot[n];
+    if (sl >= 0) order[atomicAdd(&cnt[sl], 1)] = n;  // order inside a slot is irrelevant: jobs are independent
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(1024) void grid_mfma_kernel(int hw, int N, int G, int n_chunks, const int32_t *img_idx,
+                                                         const int32_t *order, const int32_t *slot_start,
+                                                         const float *__restrict__ feat, const float *__restrict__ clu,
+                                                         const float *__restrict__ maps, float *__restrict__ partial,
+                                                         int clutter_on) {
+  __shared__ float cl[GP_TILES][GP_PIX][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, half = lane >> 5;
+  const int sl = blockIdx.x / n_chunks, c = blockIdx.x % n_chunks;
+  const int js = slot_start[sl], ns = slot_start[sl + 1] - js;
+  if (ns == 0) return;
+  const int p0 = c * GP_PIX, np = min(GP_PIX, hw - p0);
+  const int g = wave * 32 + i;
+  const bool gok = g < G;
+  const float *Bp = maps + (((size_t)sl * G + min(g, G - 1)) * hw + p0) * D + half * 4;
+  for (int tg = 0; tg < ns; tg += 32 * GP_TILES) {
+    const float *Ap[GP_TILES];
+#pragma unroll
+    for (int t = 0; t < GP_TILES; ++t) {
+      const int job = order[js + min(tg + t * 32 + i, ns - 1)];
+      const int img = img_idx ? img_idx[job] : job;
+      Ap[t] = feat + ((size_t)img * hw + p0) * D + half * 4;
+    }
+    // clutter scores of the tile's jobs at the chunk's pixels -> LDS [tile][pixel][job row]
+    for (int k = tid; k < GP_TILES * 32 * np; k += blockDim.x) {
+      const int p = k % np, row = (k / np) & 31, t = k / (np * 32);
+      const int job = order[js + min(tg + t * 32 + row, ns - 1)];
+      const int img = img_idx ? img_idx[job] : job;
+      cl[t][p][row] = clutter_on ? clu[(size_t)img * hw + p0 + p] : 0.0f;
+    }
+    __syncthreads();
+    f16v lsum[GP_TILES];
+#pragma unroll
+    for (int t = 0; t < GP_TILES; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) lsum[t][r] = 0.0f;
+    for (int p = 0; p < np; ++p) {
+      f16v acc[GP_TILES];
+#pragma unroll
+      for (int t = 0; t < GP_TILES; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+      const f4 *bq = (const f4 *)(Bp + (size_t)p * D);
+#pragma unroll 4
+      for (int q = 0; q < D / 8; ++q) {
+        const f4 b = bq[2 * q];
+#pragma unroll
+        for (int t = 0; t < GP_TILES; ++t) {
+          const f4 a = ((const f4 *)(Ap[t] + (size_t)p * D))[2 * q];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+        }
+      }
+      // C/D layout: column = lane & 31 (pose), row = (r & 3) + 8 * (r >> 2) + 4 * half (job of the tile)
+#pragma unroll
+      for (int t = 0; t < GP_TILES; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const f4 cv = *(const f4 *)&cl[t][p][8 * k + 4 * half];
+          const float cc[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float o = acc[t][4 * k + r];
+            lsum[t][4 * k + r] += clutter_on ? (fmaxf(o, cc[r]) - fmaxf(0.0f, cc[r])) : o;
+          }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < GP_TILES; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int jrow = tg + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (jrow < ns && gok) partial[((size_t)c * N + order[js + jrow]) * G + g] = lsum[t][r];
+      }
+    __syncthreads();  // the clutter tile is rewritten by the next pass
+  }
+}
+
+// loss[n][g] = K_n - (1/hw) * sum over chunks (chunk order), K_n = 1 + mean(min(clu, 0)) (loss_constant).
+__global__ __launch_bounds__(256) void grid_finish_kernel(int hw, float inv_hw, int N, int G, int n_chunks,
+                                                          const int32_t *img_idx, const int32_t *job_slot,
+                                                          const float *clu, const float *partial,
+                                                          const int32_t *pre_cnt, float *losses, u64 *counter,
+                                                          int clutter_on) {
+  __shared__ double red[256];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int sl = job_slot[n];
+  if (sl < 0) return;
+  double a = 0.0;
+  if (clutter_on) {
+    const float *c = clu + (size_t)(img_idx ? img_idx[n] : n) * hw;
+    for (int k = tid; k < hw; k += 256) a += (double)fminf(c[k], 0.0f);
+  }
+  red[tid] = a;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const float K = 1.0f + (float)red[0] * inv_hw;
+  u64 cov = 0;
+  for (int g = tid; g < G; g += 256) {
+    float s = 0.0f;
+    for (int c = 0; c < n_chunks; ++c) s += partial[((size_t)c * N + n) * G + g];
+    losses[(size_t)n * G + g] = K - inv_hw * s;
+    cov += (u64)pre_cnt[(size_t)sl * G + g];
+  }
+  if (counter && cov) atomicAdd(counter, cov);
 }
 
 // argmin over the grid losses (first minimum, torch.min semantics at
@@ -1332,7 +1503,6 @@ __global__ __launch_bounds__(NT, 4) void interp_bwd_kernel(KParams P, const Mesh
 // column and the max over clutter vectors is a max over its 16 accumulators.
 // Lane (i = l & 31, half = l >> 5) feeds feature index 8q + 4*half + c as k-step
 // 4q + c: both operands are then plain 16-byte loads.
-typedef float f16v __attribute__((ext_vector_type(16)));
 template <int D>
 __global__ __launch_bounds__(256) void clutter_kernel(const float *__restrict__ feat, size_t npix,
                                                       const float *__restrict__ cbank, int K,
@@ -1410,8 +1580,13 @@ struct nemo_ctx {
   // pre-rendered grid (nemo_grid_prerender)
   int32_t *d_pre_slot, *d_pre_cnt, *d_pre_pairs;
   uint32_t *d_pre_list;
+  float *d_pre_maps;  // dense renders [pairs][G][h*w][D] for the MFMA grid search, or null (over budget)
   const float *pre_gridC, *pre_gridT;
   int pre_G, pre_pairs;
+  // grid-search workspace (grown on demand): job grouping and per-chunk partial sums
+  int32_t *d_gs_order, *d_gs_start, *d_gs_jobslot;
+  float *d_gs_partial;
+  size_t gs_jobs_cap, gs_partial_cap;
   char err[512];
 };
 
@@ -1526,6 +1701,8 @@ int nemo_ctx_destroy(nemo_ctx *ctx) {
   hipFree(ctx->d_counter);
   hipFree(ctx->d_adam);
   hipFree(ctx->d_pre_slot); hipFree(ctx->d_pre_cnt); hipFree(ctx->d_pre_pairs); hipFree(ctx->d_pre_list);
+  hipFree(ctx->d_pre_maps); hipFree(ctx->d_gs_order); hipFree(ctx->d_gs_start); hipFree(ctx->d_gs_jobslot);
+  hipFree(ctx->d_gs_partial);
   delete ctx;
   return NEMO_OK;
 }
@@ -1645,10 +1822,47 @@ int nemo_grid_search(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const i
   const long long blocks = 8LL * ((N + 7) / 8) * ((G + GRID_POSES_PER_WG - 1) / GRID_POSES_PER_WG);
   if (blocks > 0x7fffffffLL) return fail(ctx, NEMO_ERR_UNSUPPORTED, "nemo_grid_search: N*G too large for one launch");
   PreStore pre{nullptr, nullptr, nullptr, 0};
-  if (ctx->pre_pairs > 0 && ctx->pre_G == G && ctx->pre_gridC == d_grid_C && ctx->pre_gridT == d_grid_theta)
-    pre = PreStore{ctx->d_pre_slot, ctx->d_pre_cnt, ctx->d_pre_list, (size_t)ctx->cfg.win_h * ctx->cfg.win_w};
+  const bool store_ok = ctx->pre_pairs > 0 && ctx->pre_G == G && ctx->pre_gridC == d_grid_C && ctx->pre_gridT == d_grid_theta;
+  if (store_ok) pre = PreStore{ctx->d_pre_slot, ctx->d_pre_cnt, ctx->d_pre_list, (size_t)ctx->cfg.win_h * ctx->cfg.win_w};
+  const char *no_mfma = getenv("NEMO_GRID_NO_MFMA");
+  const bool mfma = store_ok && ctx->d_pre_maps && !(no_mfma && atoi(no_mfma));
+  if (mfma) {
+    // matrix-core path over the dense pre-rendered maps; jobs without a stored pair fall through to grid_kernel
+    const int hw = ctx->cfg.win_h * ctx->cfg.win_w, n_chunks = (hw + GP_PIX - 1) / GP_PIX;
+    const size_t need_partial = (size_t)n_chunks * N * G;
+    if ((size_t)N > ctx->gs_jobs_cap) {
+      hipFree(ctx->d_gs_order); hipFree(ctx->d_gs_jobslot); hipFree(ctx->d_gs_start);
+      ctx->d_gs_order = ctx->d_gs_jobslot = ctx->d_gs_start = nullptr;
+      ctx->gs_jobs_cap = 0;
+      HIP_TRY(ctx, hipMalloc(&ctx->d_gs_order, sizeof(int32_t) * N));
+      HIP_TRY(ctx, hipMalloc(&ctx->d_gs_jobslot, sizeof(int32_t) * N));
+      HIP_TRY(ctx, hipMalloc(&ctx->d_gs_start, sizeof(int32_t) * (GP_MAX_PAIRS + 1)));
+      ctx->gs_jobs_cap = (size_t)N;
+    }
+    if (need_partial > ctx->gs_partial_cap) {
+      hipFree(ctx->d_gs_partial);
+      ctx->d_gs_partial = nullptr;
+      ctx->gs_partial_cap = 0;
+      HIP_TRY(ctx, hipMalloc(&ctx->d_gs_partial, sizeof(float) * need_partial));
+      ctx->gs_partial_cap = need_partial;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(grid_group_kernel, dim3(1), dim3(1024), 0, st, N, d_mesh_idx, d_grid_idx, ctx->d_pre_slot,
+                       ctx->pre_pairs, ctx->d_gs_order, ctx->d_gs_start, ctx->d_gs_jobslot);
+    const dim3 grd((unsigned)(ctx->pre_pairs * n_chunks)), blk((unsigned)(64 * ((G + 31) / 32)));
+    const int con = (ctx->cfg.clutter && d_clu) ? 1 : 0;
+    if (ctx->cfg.feat_dim == 128)
+      hipLaunchKernelGGL((grid_mfma_kernel<128>), grd, blk, 0, st, hw, N, G, n_chunks, d_img_idx, ctx->d_gs_order,
+                         ctx->d_gs_start, d_feat, d_clu, ctx->d_pre_maps, ctx->d_gs_partial, con);
+    else
+      hipLaunchKernelGGL((grid_mfma_kernel<256>), grd, blk, 0, st, hw, N, G, n_chunks, d_img_idx, ctx->d_gs_order,
+                         ctx->d_gs_start, d_feat, d_clu, ctx->d_pre_maps, ctx->d_gs_partial, con);
+    hipLaunchKernelGGL(grid_finish_kernel, dim3(N), dim3(256), 0, st, hw, ctx->P.inv_hw, N, G, n_chunks, d_img_idx,
+                       ctx->d_gs_jobslot, d_clu, ctx->d_gs_partial, ctx->d_pre_cnt, d_losses, ctx->d_counter, con);
+    HIP_TRY(ctx, hipGetLastError());
+  }
   DISPATCH_DP(grid_kernel, dim3((unsigned)blocks), ctx->P, ctx->d_meshes, N, d_img_idx, d_mesh_idx, d_grid_idx, d_feat,
-              d_clu, d_grid_C, d_grid_theta, G, d_losses, ctx->d_counter, pre);
+              d_clu, d_grid_C, d_grid_theta, G, d_losses, ctx->d_counter, pre, mfma ? 1 : 0);
   HIP_TRY(ctx, hipGetLastError());
   hipLaunchKernelGGL(grid_argmin_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, N, G, d_losses, d_grid_idx,
                      d_grid_C, d_grid_theta, d_C0, d_theta0, d_best);
@@ -1660,8 +1874,10 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
                         const int32_t *h_pair_mesh, const int32_t *h_pair_grid, int32_t n_pairs, void *stream) {
   if (!ctx) return fail(nullptr, NEMO_ERR_ARG, "nemo_grid_prerender: null ctx");
   hipFree(ctx->d_pre_slot); hipFree(ctx->d_pre_cnt); hipFree(ctx->d_pre_pairs); hipFree(ctx->d_pre_list);
+  hipFree(ctx->d_pre_maps);
   ctx->d_pre_slot = ctx->d_pre_cnt = ctx->d_pre_pairs = nullptr;
   ctx->d_pre_list = nullptr;
+  ctx->d_pre_maps = nullptr;
   ctx->pre_pairs = 0;
   if (n_pairs == 0) return NEMO_OK;  // store dropped
   if (!d_grid_C || !d_grid_theta || !h_pair_mesh || !h_pair_grid || n_pairs < 0 || G <= 0 || n_grids <= 0)
@@ -1694,6 +1910,54 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
   HIP_TRY(ctx, hipGetLastError());
   ctx->pre_gridC = d_grid_C; ctx->pre_gridT = d_grid_theta;
   ctx->pre_G = G; ctx->pre_pairs = n_pairs;
+  // Dense renders for the MFMA grid search: campos -> rasterize -> interpolate with the standalone kernels
+  // (uncovered pixels are zero rows).  Skipped when they would not fit the budget (NEMO_PRERENDER_MAP_GB,
+  // default 48): the list path above then serves the grid search.
+  {
+    const char *env = getenv("NEMO_PRERENDER_MAP_GB");
+    const double budget = (env ? atof(env) : 48.0) * 1073741824.0;
+    const size_t jobs = (size_t)n_pairs * G, D = (size_t)ctx->cfg.feat_dim;
+    const double need = (double)jobs * stride * D * 4.0;
+    if (need <= budget && n_pairs <= GP_MAX_PAIRS && G <= 512) {
+      std::vector<int32_t> h_mesh(jobs), h_gidx(jobs);
+      std::vector<float> h_C, h_t;
+      for (int i = 0; i < n_pairs; ++i)
+        for (int g = 0; g < G; ++g) { h_mesh[(size_t)i * G + g] = h_pair_mesh[i]; h_gidx[(size_t)i * G + g] = h_pair_grid[i] * G + g; }
+      int32_t *d_mesh = nullptr, *d_gidx = nullptr, *d_p2f = nullptr;
+      float *d_C = nullptr, *d_t = nullptr, *d_R = nullptr, *d_T = nullptr, *d_bary = nullptr;
+      hipStream_t st = (hipStream_t)stream;
+      auto cleanup = [&]() { hipFree(d_mesh); hipFree(d_gidx); hipFree(d_p2f); hipFree(d_C); hipFree(d_t); hipFree(d_R); hipFree(d_T); hipFree(d_bary); };
+      hipError_t e = hipMalloc(&d_mesh, jobs * 4);
+      if (e == hipSuccess) e = hipMalloc(&d_gidx, jobs * 4);
+      if (e == hipSuccess) e = hipMalloc(&d_C, jobs * 12);
+      if (e == hipSuccess) e = hipMalloc(&d_t, jobs * 4);
+      if (e == hipSuccess) e = hipMalloc(&d_R, jobs * 36);
+      if (e == hipSuccess) e = hipMalloc(&d_T, jobs * 12);
+      if (e == hipSuccess) e = hipMalloc(&d_p2f, jobs * stride * 4);
+      if (e == hipSuccess) e = hipMalloc(&d_bary, jobs * stride * 12);
+      if (e == hipSuccess) e = hipMalloc(&ctx->d_pre_maps, (size_t)need);
+      if (e == hipSuccess) e = hipMemcpyAsync(d_mesh, h_mesh.data(), jobs * 4, hipMemcpyHostToDevice, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(d_gidx, h_gidx.data(), jobs * 4, hipMemcpyHostToDevice, st);
+      if (e != hipSuccess) { cleanup(); hipFree(ctx->d_pre_maps); ctx->d_pre_maps = nullptr; return hip_fail(ctx, e, "nemo_grid_prerender: maps"); }
+      hipLaunchKernelGGL(gather_pose_kernel, dim3((unsigned)((jobs + 255) / 256)), dim3(256), 0, st, (int)jobs, d_gidx,
+                         d_grid_C, d_grid_theta, d_C, d_t);
+      hipLaunchKernelGGL(campos_kernel, dim3((unsigned)((jobs + 63) / 64)), dim3(64), 0, st, d_C, d_t, (const float *)nullptr,
+                         (int)jobs, d_R, d_T);
+      if (ctx->P.persp)
+        hipLaunchKernelGGL((raster_kernel<true>), dim3((unsigned)jobs), dim3(NT), ctx->lds, st, ctx->P, ctx->d_meshes, d_mesh,
+                           d_R, d_T, d_p2f, d_bary, (float *)nullptr);
+      else
+        hipLaunchKernelGGL((raster_kernel<false>), dim3((unsigned)jobs), dim3(NT), ctx->lds, st, ctx->P, ctx->d_meshes, d_mesh,
+                           d_R, d_T, d_p2f, d_bary, (float *)nullptr);
+      const size_t npix = jobs * stride, threads = npix * (D / 4);
+      hipLaunchKernelGGL(interpolate_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (int)D, npix, stride,
+                         ctx->d_meshes, d_mesh, d_p2f, d_bary, ctx->d_pre_maps);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      cleanup();
+      if (e != hipSuccess) { hipFree(ctx->d_pre_maps); ctx->d_pre_maps = nullptr; return hip_fail(ctx, e, "nemo_grid_prerender: render maps"); }
+    }
+  }
   return NEMO_OK;
 }
 

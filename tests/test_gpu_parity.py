@@ -188,10 +188,13 @@ def test_grid_search(oracle):
 
 
 @pytest.mark.parametrize('persp', [False, True])
-def test_grid_search_prerendered(oracle, persp):
-    """get_pre_render_samples path (code/MeshPoseSolveAll.py:62-100): coverage rendered once per
-    (mesh, pose), then consumed per image.  Same losses (bit for bit: the list the score loop walks is
-    the same) and the same first minimum as the on-the-fly path, and parity with the oracle."""
+@pytest.mark.parametrize('mfma', [True, False])
+def test_grid_search_prerendered(oracle, persp, mfma, monkeypatch):
+    """get_pre_render_samples path (code/MeshPoseSolveAll.py:62-100): every grid pose rendered once per
+    (mesh, pose), then compared with each image.  Two consumers of the store: the matrix-core kernel over
+    dense rendered maps (default) and the list path (NEMO_GRID_NO_MFMA=1; bit-identical to rendering on the
+    fly because the score loop walks the same list).  Both: parity with the oracle, same first minimum."""
+    monkeypatch.setenv('NEMO_GRID_NO_MFMA', '0' if mfma else '1')
     sc = make_scene(n_img=3, perspective_correct=persp)
     eng = _engine(sc)
     gC, gth = syn.pose_grid(sc.distance)
@@ -199,19 +202,50 @@ def test_grid_search_prerendered(oracle, persp):
     feats, clus = _dev(sc.feats), _dev(sc.clus)
     _, _, best0, losses0 = eng.grid_search(feats, clus, dC, dth)
     eng.grid_prerender(dC, dth, [(0, 0)])
+    eng.counter_reset()
     C0, th0, best1, losses1 = eng.grid_search(feats, clus, dC, dth)
-    assert torch.equal(losses0, losses1) and torch.equal(best0, best1)
+    cov1 = eng.counter_read()
+    if mfma:
+        assert (losses0 - losses1).abs().max().item() <= 1e-5 and torch.equal(best0, best1)
+    else:
+        assert torch.equal(losses0, losses1) and torch.equal(best0, best1)
     for i in range(3):
         bo, lo = oracle.grid_search(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[i], sc.clus[i], gC, gth)
         assert np.abs(losses1[i].cpu().numpy() - lo).max() <= REL * np.abs(lo).max()
         assert best1[i].item() == bo
-    # another grid buffer (same values): the store does not apply, results are unchanged
+        assert np.array_equal(C0[i].cpu().numpy(), gC[bo]) and th0[i].item() == gth[bo]
+    # another grid buffer (same values): the store does not apply, results are those of the on-the-fly path
     dC2 = dC.clone()
+    eng.counter_reset()
     _, _, best2, losses2 = eng.grid_search(feats, clus, dC2, dth)
-    assert torch.equal(losses2, losses1) and torch.equal(best2, best1)
+    assert eng.counter_read() == cov1          # same covered-pixel accounting either way
+    assert torch.equal(losses2, losses0) and torch.equal(best2, best0)
     eng.grid_prerender(None, None, [])  # drop
     _, _, best3, losses3 = eng.grid_search(feats, clus, dC, dth)
-    assert torch.equal(losses3, losses1) and torch.equal(best3, best1)
+    assert torch.equal(losses3, losses0) and torch.equal(best3, best0)
+
+
+def test_grid_search_prerendered_mixed_jobs(oracle):
+    """Two meshes, only one of them pre-rendered, jobs interleaved and images reused: prepared jobs go
+    through the matrix-core kernel, the others are rendered on the fly, in one call."""
+    a, b = make_scene(n_img=2, seed=31), make_scene(n_img=2, seed=32, jitter=np.array([1.1, 0.95, 1.0]), clutter=True)
+    eng = _engine(a)
+    eng.register_mesh(b.verts, b.faces, b.bank)
+    gC, gth = syn.pose_grid(a.distance)
+    dC, dth = _dev(np.stack([gC, gC])), _dev(np.stack([gth, gth]))
+    feats, clus = _dev(np.concatenate([a.feats, b.feats])), _dev(np.concatenate([a.clus, b.clus]))
+    img = np.array([0, 2, 1, 3, 0, 3], np.int32)
+    mesh = np.array([0, 1, 0, 1, 0, 1], np.int32)
+    eng.grid_prerender(dC, dth, [(1, 1)])
+    _, _, best, losses = eng.grid_search(feats, clus, dC, dth, img_idx=_dev(img, torch.int32), mesh_idx=_dev(mesh, torch.int32),
+                                         grid_idx=_dev(mesh, torch.int32))
+    best, losses = best.cpu().numpy(), losses.cpu().numpy()
+    for k in range(6):
+        sc = (a, b)[mesh[k]]
+        f, c = (np.concatenate([a.feats, b.feats]))[img[k]], (np.concatenate([a.clus, b.clus]))[img[k]]
+        bo, lo = oracle.grid_search(sc.cfg, sc.verts, sc.faces, sc.bank, f, c, gC, gth)
+        assert np.abs(losses[k] - lo).max() <= REL * np.abs(lo).max()
+        assert best[k] == bo
 
 
 @pytest.mark.parametrize('persp', [False, True])
