@@ -1245,7 +1245,7 @@ __global__ __launch_bounds__(1024) void grid_mfma_kernel(int hw, int N, int G, i
   const int js = slot_start[sl], ns = slot_start[sl + 1] - js;
   if (ns == 0) return;
   const int p0 = c * GP_PIX, np = min(GP_PIX, hw - p0);
-  const int g = wave * 32 + i;
+  const int g = (int)blockIdx.y * 512 + wave * 32 + i;  // 16 waves x 32 poses per workgroup, more poses in grid.y
   const bool gok = g < G;
   const float *Bp = maps + (((size_t)sl * G + min(g, G - 1)) * hw + p0) * D + half * 4;
   for (int tg = 0; tg < ns; tg += 32 * GP_TILES) {
@@ -1849,7 +1849,8 @@ int nemo_grid_search(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const i
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(grid_group_kernel, dim3(1), dim3(1024), 0, st, N, d_mesh_idx, d_grid_idx, ctx->d_pre_slot,
                        ctx->pre_pairs, ctx->d_gs_order, ctx->d_gs_start, ctx->d_gs_jobslot);
-    const dim3 grd((unsigned)(ctx->pre_pairs * n_chunks)), blk((unsigned)(64 * ((G + 31) / 32)));
+    const int gy = (G + 511) / 512;  // poses beyond 512 go to further workgroups (grid.y)
+    const dim3 grd((unsigned)(ctx->pre_pairs * n_chunks), (unsigned)gy), blk((unsigned)(64 * (((G < 512 ? G : 512) + 31) / 32)));
     const int con = (ctx->cfg.clutter && d_clu) ? 1 : 0;
     if (ctx->cfg.feat_dim == 128)
       hipLaunchKernelGGL((grid_mfma_kernel<128>), grd, blk, 0, st, hw, N, G, n_chunks, d_img_idx, ctx->d_gs_order,
@@ -1918,7 +1919,7 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
     const double budget = (env ? atof(env) : 48.0) * 1073741824.0;
     const size_t jobs = (size_t)n_pairs * G, D = (size_t)ctx->cfg.feat_dim;
     const double need = (double)jobs * stride * D * 4.0;
-    if (need <= budget && n_pairs <= GP_MAX_PAIRS && G <= 512) {
+    if (need <= budget && n_pairs <= GP_MAX_PAIRS) {
       std::vector<int32_t> h_mesh(jobs), h_gidx(jobs);
       std::vector<float> h_C, h_t;
       for (int i = 0; i < n_pairs; ++i)

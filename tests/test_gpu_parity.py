@@ -560,3 +560,24 @@ def test_solve_all_runner_from_files(tmp_path):
                            '--image_size', '256,384', '--six_dof', '--save_final_pred', pred_path]) == 0
     with np.load(pred_path) as z:
         assert sorted(z.files) == sorted(feats) and all(z[n].shape == (6,) and np.all(np.isfinite(z[n])) for n in z.files)
+
+
+def test_dense_pose_grid_search(oracle):
+    """BASELINE config 4 shape (dense azimuth x elevation x theta x distance grid), scaled to a size the
+    oracle finishes in seconds: 24 x 6 x 5 x 4 = 2880 poses per image through the pre-rendered matrix-core
+    path (more than 512 poses: several pose blocks per workgroup column), every loss against the oracle."""
+    sc = make_scene(image_hw=(128, 192), number_vertices=150, n_img=2, seed=41)
+    eng = _engine(sc)
+    d = sc.distance
+    gC, gth = syn.pose_grid(d, n_azim=24, n_elev=6, n_theta=5, distances=(0.85 * d, 0.95 * d, 1.05 * d, 1.15 * d))
+    assert len(gth) == 2880
+    dC, dth = _dev(gC[None]), _dev(gth[None])
+    feats, clus = _dev(sc.feats), _dev(sc.clus)
+    eng.grid_prerender(dC, dth, [(0, 0)])
+    C0, th0, best, losses = eng.grid_search(feats, clus, dC, dth)
+    best, losses = best.cpu().numpy(), losses.cpu().numpy()
+    assert np.isfinite(losses).all()
+    for i in range(2):
+        bo, lo = oracle.grid_search(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[i], sc.clus[i], gC, gth)
+        assert np.abs(losses[i] - lo).max() <= REL * np.abs(lo).max()
+        assert best[i] == bo
