@@ -81,6 +81,12 @@ struct KParams {
   int fmax;  // face capacity of the LDS arrays
   unsigned w_magic;  // floor(2^32 / w) + 1: p / w == umulhi(p, w_magic) for p, w < 2^16
   int zb_bytes;      // z-buffer region: max(8*cap, chunk partials + phase A->B hand-off buffer)
+  // Large meshes (their per-vertex / per-face tables do not fit the LDS next to a useful z-buffer): the tables
+  // live in a per-workgroup slice of a global scratch buffer instead (L2-resident), selected by the BIG
+  // template parameter of the kernels.
+  int big;
+  unsigned big_stride;            // bytes per workgroup slice
+  unsigned long long big_scratch; // device address of slice 0
 };
 
 // ---------------------------------------------------------------- small math
@@ -352,6 +358,9 @@ struct Lds {
   f4 *sv;                // [vmax] screen verts (u, t, z_view, -)
   us4 *fc;               // [fmax] face vertex ids (i0, i1, i2, -) as 16-bit
   us4 *finfo;            // [fmax] per face, per band: box (a_lo, a_hi, b_lo, b_hi) of its fragments
+  __attribute__((address_space(1))) f4 *gsv;     // BIG: the same three tables in global scratch
+  __attribute__((address_space(1))) us4 *gfc;
+  __attribute__((address_space(1))) us4 *gfinfo;
   float *ndc;            // [S] pixel-centre NDC coordinate of flipped index a: PixToNdc(a, S)
   uint32_t *list;        // [cap] covered pixels, face-major: (face id << 16) | window pixel index
   float *red;            // [NW][RED_N]
@@ -409,14 +418,26 @@ __device__ __forceinline__ Lds lds_carve(unsigned char *base, const KParams &P) 
   Lds L;
   L.zb = (u64 *)base;
   L.sv = (f4 *)(base + (size_t)P.zb_bytes);
-  L.fc = (us4 *)(L.sv + P.vmax);
-  L.finfo = L.fc + P.fmax;
-  L.list = (uint32_t *)(L.finfo + P.fmax);
+  const int vl = P.big ? 0 : P.vmax, fl = P.big ? 0 : P.fmax;  // table entries kept in LDS
+  L.fc = (us4 *)(L.sv + vl);
+  L.finfo = L.fc + fl;
+  L.list = (uint32_t *)(L.finfo + fl);
   L.red = (float *)(L.list + P.cap);
   L.ust = L.red + NW * RED_N;
   L.ndc = L.ust + UST_N + 2;  // indices -2 .. S+1
+  unsigned char *g = (unsigned char *)(P.big_scratch + (unsigned long long)blockIdx.x * P.big_stride);
+  L.gsv = (__attribute__((address_space(1))) f4 *)g;
+  L.gfc = (__attribute__((address_space(1))) us4 *)(g + (size_t)P.vmax * 16);
+  L.gfinfo = L.gfc + P.fmax;
   return L;
 }
+// Table accessors: LDS for ordinary meshes, the global scratch slice for BIG ones.
+template <bool BIG> __device__ __forceinline__ f4 sv_at(const Lds &L, int i) { if constexpr (BIG) return L.gsv[i]; else return L.sv[i]; }
+template <bool BIG> __device__ __forceinline__ void sv_put(const Lds &L, int i, f4 v) { if constexpr (BIG) L.gsv[i] = v; else L.sv[i] = v; }
+template <bool BIG> __device__ __forceinline__ us4 fc_at(const Lds &L, int i) { if constexpr (BIG) return L.gfc[i]; else return L.fc[i]; }
+template <bool BIG> __device__ __forceinline__ void fc_put(const Lds &L, int i, us4 v) { if constexpr (BIG) L.gfc[i] = v; else L.fc[i] = v; }
+template <bool BIG> __device__ __forceinline__ us4 finfo_at(const Lds &L, int i) { if constexpr (BIG) return L.gfinfo[i]; else return L.finfo[i]; }
+template <bool BIG> __device__ __forceinline__ void finfo_put(const Lds &L, int i, us4 v) { if constexpr (BIG) L.gfinfo[i] = v; else L.finfo[i] = v; }
 
 constexpr int MAX_GRIDS = 64;
 constexpr int GRID_POSES_PER_WG = 4;
@@ -436,8 +457,9 @@ struct EmitOut {  // standalone rasterizer outputs (window), may be null
   int pre_cnt;
 };
 
+template <bool BIG>
 __device__ __forceinline__ void load_face_verts(const Lds &L, int i0, int i1, int i2, float *v) {
-  const f4 s0 = L.sv[i0], s1 = L.sv[i1], s2 = L.sv[i2];
+  const f4 s0 = sv_at<BIG>(L, i0), s1 = sv_at<BIG>(L, i1), s2 = sv_at<BIG>(L, i2);
   v[0] = s0.x; v[1] = s0.y; v[2] = s0.z;
   v[3] = s1.x; v[4] = s1.y; v[5] = s1.z;
   v[6] = s2.x; v[7] = s2.y; v[8] = s2.z;
@@ -452,7 +474,7 @@ __device__ __forceinline__ float block_total(const Lds &L, int i) { return L.ust
 // RAW = true: `feat` holds an upstream gradient dL/d(out) [h][w][D] of the
 // interpolated map and the routine back-propagates it (module path); otherwise
 // `feat` is the image feature map and the loss of MeshPoseSolveAll.py:58-59 is used.
-template <int D, bool PERSP, bool GRAD, bool SCORE, bool RAW = false, bool PRE = false>
+template <int D, bool PERSP, bool GRAD, bool SCORE, bool RAW = false, bool PRE = false, bool BIG = false>
 __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, const float *__restrict__ feat,
                           const float *__restrict__ clu, EmitOut emit) {
 #ifndef NEMO_KIT
@@ -486,7 +508,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       const float yc = ((x * m01 + y * m11) + z * m21) + m31;
       const float zv = ((x * r02 + y * r12) + z * r22) + t2;
       const float u = xc / zv, t = yc / zv;
-      L.sv[v] = f4{u, t, zv, 0.0f};
+      sv_put<BIG>(L, v, f4{u, t, zv, 0.0f});
       umin = fminf(umin, u); umax = fmaxf(umax, u);
       tmin = fminf(tmin, t); tmax = fmaxf(tmax, t);
     }
@@ -549,9 +571,9 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
         const int p = (int)(ent & 0xffffu), f = (int)(ent >> 16);
         const int i = (int)__umulhi((unsigned)p, P.w_magic), j = p - i * P.w;
         const int a = S - 1 - (j + P.c0), b = S - 1 - (i + P.r0);
-        const us4 fv_ = L.fc[f];
+        const us4 fv_ = fc_at<BIG>(L, f);
         float v[9];
-        load_face_verts(L, fv_.x, fv_.y, fv_.z, v);
+        load_face_verts<BIG>(L, fv_.x, fv_.y, fv_.z, v);
         Frag fr;
         fr.b0 = fr.b1 = fr.b2 = fr.pz = -1.0f;
         frag_eval<PERSP>(L.ndc[a], L.ndc[b], v, face_area_eps(v, P.keps), fr);
@@ -625,7 +647,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
           ent_bs[u] = ent;
           cls[u] = (P.clutter && clu) ? gclu[ent & 0xffffu] : 0.0f;
           if (u * 64 < cn) {
-            const us4 fv_ = L.fc[ent >> 16];
+            const us4 fv_ = fc_at<BIG>(L, ent >> 16);
             rec[u * 64 + lane] = uint4{(ent & 0xffffu) * (uint32_t)(D * 4), (uint32_t)fv_.x | ((uint32_t)fv_.y << 16),
                                        (uint32_t)fv_.z, 0u};
           }
@@ -719,11 +741,11 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
           const int p = (int)(ent_b & 0xffffu), f = (int)(ent_b >> 16);
           const int pi = (int)__umulhi((unsigned)p, P.w_magic), pj = p - pi * P.w;
           const int a = S - 1 - (pj + P.c0), b = S - 1 - (pi + P.r0);
-          const us4 fv_ = L.fc[f];
+          const us4 fv_ = fc_at<BIG>(L, f);
           const int i0 = fv_.x, i1 = fv_.y, i2 = fv_.z;
           const float g0 = gbuf[3 * lb], g1 = gbuf[3 * lb + 1], g2 = gbuf[3 * lb + 2];
           float v[9];
-          load_face_verts(L, i0, i1, i2, v);
+          load_face_verts<BIG>(L, i0, i1, i2, v);
           const float px = L.ndc[a], py = L.ndc[b];
           // coverage was decided (exactly) by the rasterizer; the quantities below only feed the
           // 1e-4-tolerance loss and gradient, so reciprocals replace IEEE divisions here
@@ -854,10 +876,10 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       STAMP(1);
       // ---- 2b. face-parallel rasterisation (one thread per face)
       for (int f = tid; f < F; f += NT) {
-        const us4 fv_ = L.fc[f];
+        const us4 fv_ = fc_at<BIG>(L, f);
         const int i0 = fv_.x, i1 = fv_.y, i2 = fv_.z;
         float v[9];
-        load_face_verts(L, i0, i1, i2, v);
+        load_face_verts<BIG>(L, i0, i1, i2, v);
         // box of the pixels where this face produced a fragment (empty: lo > hi); the list walks
         // below look only there
         int ha_lo = 1, ha_hi = 0, hb_lo = 1, hb_hi = 0;
@@ -886,7 +908,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
             if (ha_hi < 0) { ha_lo = hb_lo = 1; ha_hi = hb_hi = 0; }
           }
         }
-        L.finfo[f] = us4{(unsigned short)ha_lo, (unsigned short)ha_hi, (unsigned short)hb_lo, (unsigned short)hb_hi};
+        finfo_put<BIG>(L, f, us4{(unsigned short)ha_lo, (unsigned short)ha_hi, (unsigned short)hb_lo, (unsigned short)hb_hi});
       }
       __syncthreads();
       STAMP(2);
@@ -900,7 +922,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       const int fbeg = min(F, tid * fpl), fend = min(F, fbeg + fpl);
       auto walk = [&](auto &&visit) {
         for (int f = fbeg; f < fend; ++f) {
-          const us4 fi = L.finfo[f];
+          const us4 fi = finfo_at<BIG>(L, f);
           const int fa_lo = fi.x, fa_hi = fi.y, fb_lo = fi.z, fb_hi = fi.w;
           for (int b = fb_lo; b <= fb_hi; ++b)
             for (int a = fa_lo; a <= fa_hi; ++a)
@@ -985,11 +1007,12 @@ __device__ void loss_constant(const KParams &P, const Lds &L, const float *__res
 
 // Per-kernel LDS set-up: face vertex ids as 8-byte records and the table of pixel-centre
 // NDC coordinates (the exact PixToNdc values, computed once instead of per pixel test).
+template <bool BIG>
 __device__ __forceinline__ void load_world_verts(const KParams &P, const Lds &L, const MeshDesc &M) {
   const gi32p gf = as_global(M.faces);
   const gf32p gv = as_global(M.verts);
   for (int i = threadIdx.x; i < M.F; i += NT)
-    L.fc[i] = us4{(unsigned short)gf[3 * i], (unsigned short)gf[3 * i + 1], (unsigned short)gf[3 * i + 2], 0};
+    fc_put<BIG>(L, i, us4{(unsigned short)gf[3 * i], (unsigned short)gf[3 * i + 1], (unsigned short)gf[3 * i + 2], 0});
   for (int i = (int)threadIdx.x - 2; i < P.S + 2; i += NT) L.ndc[i] = ndc_of(i, (float)P.S);
   __syncthreads();
 }
@@ -1036,7 +1059,7 @@ __global__ void campos_kernel(const float *C, const float *theta, const float *e
   for (int i = 0; i < 3; ++i) T[3 * n + i] = k.T[i];
 }
 
-template <bool PERSP>
+template <bool PERSP, bool BIG>
 __global__ __launch_bounds__(NT, 4) void raster_kernel(KParams P, const MeshDesc *meshes, const int32_t *mesh_idx,
                                                        const float *Rs, const float *Ts, int32_t *p2f, float *bary,
                                                        float *zbuf) {
@@ -1052,12 +1075,12 @@ __global__ __launch_bounds__(NT, 4) void raster_kernel(KParams P, const MeshDesc
   }
   if (threadIdx.x < 9) L.ust[U_R + threadIdx.x] = Rs[9 * n + threadIdx.x];
   if (threadIdx.x < 3) L.ust[U_T + threadIdx.x] = Ts[3 * n + threadIdx.x];
-  load_world_verts(P, L, M);  // ends with a barrier
-  eval_pose<128, PERSP, false, false>(P, L, M, nullptr, nullptr, emit);
+  load_world_verts<BIG>(P, L, M);  // ends with a barrier
+  eval_pose<128, PERSP, false, false, false, false, BIG>(P, L, M, nullptr, nullptr, emit);
 }
 
 // One evaluation per job at given poses (teacher-forced parity entry point).
-template <int D, bool PERSP>
+template <int D, bool PERSP, bool BIG>
 __global__ __launch_bounds__(NT, 4) void score_kernel(KParams P, const MeshDesc *meshes, const int32_t *img_idx,
                                                       const int32_t *mesh_idx, const float *feat, const float *clu,
                                                       const float *Cs, const float *thetas, float *loss, float *grad,
@@ -1069,7 +1092,7 @@ __global__ __launch_bounds__(NT, 4) void score_kernel(KParams P, const MeshDesc 
   const float *f = feat + (size_t)img * hw * D;
   const float *c = clu ? clu + (size_t)img * hw : nullptr;
   const Lds L = lds_carve(smem, P);
-  load_world_verts(P, L, M);
+  load_world_verts<BIG>(P, L, M);
   loss_constant(P, L, c);
   if (threadIdx.x == 0) {
     const float Cp[3] = {Cs[3 * n], Cs[3 * n + 1], Cs[3 * n + 2]};
@@ -1078,7 +1101,7 @@ __global__ __launch_bounds__(NT, 4) void score_kernel(KParams P, const MeshDesc 
   }
   __syncthreads();
   EmitOut none{nullptr, nullptr, nullptr};
-  eval_pose<D, PERSP, true, true>(P, L, M, f, c, none);
+  eval_pose<D, PERSP, true, true, false, false, BIG>(P, L, M, f, c, none);
   if (threadIdx.x == 0) {
     loss[n] = L.ust[U_K] - P.inv_hw * block_total(L, 0);
     const int nc = (int)(block_total(L, T_NCOV) + 0.5f);
@@ -1098,7 +1121,7 @@ __global__ __launch_bounds__(NT, 4) void score_kernel(KParams P, const MeshDesc 
 // Pre-render (get_pre_render_samples, code/MeshPoseSolveAll.py:62-82): the coverage of a grid pose
 // depends on the mesh and the pose only, so its face-major list is built once per (mesh, grid, pose)
 // and every image's grid search consumes it.  One workgroup per (pair, pose).
-template <bool PERSP>
+template <bool PERSP, bool BIG>
 __global__ __launch_bounds__(NT, 4) void prerender_kernel(KParams P, const MeshDesc *meshes, const int32_t *pair_mesh,
                                                           const int32_t *pair_grid, const float *gridC,
                                                           const float *gridTheta, int G, uint32_t *list, int32_t *cnt,
@@ -1107,7 +1130,7 @@ __global__ __launch_bounds__(NT, 4) void prerender_kernel(KParams P, const MeshD
   const MeshDesc M = meshes[pair_mesh[sl]];
   const int gi = pair_grid[sl];
   const Lds L = lds_carve(smem, P);
-  load_world_verts(P, L, M);
+  load_world_verts<BIG>(P, L, M);
   if (threadIdx.x == 0) {
     const float *gc = gridC + ((size_t)gi * G + g) * 3;
     const float Cp[3] = {gc[0], gc[1], gc[2]};
@@ -1117,7 +1140,7 @@ __global__ __launch_bounds__(NT, 4) void prerender_kernel(KParams P, const MeshD
   __syncthreads();
   EmitOut e{};
   e.list_out = list + (size_t)blockIdx.x * stride;
-  eval_pose<128, PERSP, false, false>(P, L, M, nullptr, nullptr, e);
+  eval_pose<128, PERSP, false, false, false, false, BIG>(P, L, M, nullptr, nullptr, e);
   if (threadIdx.x == 0) cnt[blockIdx.x] = (int)(block_total(L, T_NCOV) + 0.5f);
 }
 
@@ -1125,14 +1148,15 @@ __global__ __launch_bounds__(NT, 4) void prerender_kernel(KParams P, const MeshD
 // all poses of one image run on the same XCD at about the same time (blocks b
 // and b+8 share an XCD under round-robin dispatch; L2 affinity only, never
 // correctness): the image's feature rows are then served from that XCD's L2.
-template <int D, bool PERSP>
+template <int D, bool PERSP, bool BIG>
 __global__ __launch_bounds__(NT, 4) void grid_kernel(KParams P, const MeshDesc *meshes, int N, const int32_t *img_idx,
                                                      const int32_t *mesh_idx, const int32_t *grid_idx,
                                                      const float *feat, const float *clu, const float *gridC,
                                                      const float *gridTheta, int G, float *losses, u64 *counter,
-                                                     PreStore pre, int skip_prepared) {
+                                                     PreStore pre, int skip_prepared, unsigned block_base) {
   const int GB = (G + GRID_POSES_PER_WG - 1) / GRID_POSES_PER_WG;
-  const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+  const unsigned bid = blockIdx.x + block_base;  // large meshes: launches are sliced, the scratch slice is blockIdx.x
+  const int xcd = bid & 7, k = bid >> 3;
   const int n = (k / GB) * 8 + xcd, g0 = (k % GB) * GRID_POSES_PER_WG;
   if (n >= N) return;
   const int mi = mesh_idx ? mesh_idx[n] : 0;
@@ -1145,7 +1169,7 @@ __global__ __launch_bounds__(NT, 4) void grid_kernel(KParams P, const MeshDesc *
   const float *f = feat + (size_t)img * hw * D;
   const float *c = clu ? clu + (size_t)img * hw : nullptr;
   const Lds L = lds_carve(smem, P);
-  load_world_verts(P, L, M);
+  load_world_verts<BIG>(P, L, M);
   loss_constant(P, L, c);
   u64 ncov_sum = 0;
   // a workgroup walks a few consecutive poses of its image: the per-image set-up is paid once
@@ -1162,10 +1186,10 @@ __global__ __launch_bounds__(NT, 4) void grid_kernel(KParams P, const MeshDesc *
       const size_t pg = (size_t)slot * G + g;
       e.pre_list = pre.list + pg * pre.stride;
       e.pre_cnt = pre.cnt[pg];
-      eval_pose<D, PERSP, false, true, false, true>(P, L, M, f, c, e);
+      eval_pose<D, PERSP, false, true, false, true, BIG>(P, L, M, f, c, e);
     } else {
       EmitOut none{};
-      eval_pose<D, PERSP, false, true>(P, L, M, f, c, none);
+      eval_pose<D, PERSP, false, true, false, false, BIG>(P, L, M, f, c, none);
     }
     if (threadIdx.x == 0) {
       losses[(size_t)n * G + g] = L.ust[U_K] - P.inv_hw * block_total(L, 0);
@@ -1374,7 +1398,7 @@ __global__ void grid_argmin_kernel(int N, int G, const float *losses, const int3
 // The fused solve: code/MeshPoseSolveAll.py:227-250 in one launch.  Thread 0
 // runs the serial part of every step (camera, camera backward, Adam) and hands
 // R, T to the workgroup through LDS; (C, theta) and the Adam moments live in LDS.
-template <int D, bool PERSP>
+template <int D, bool PERSP, bool BIG>
 __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc *meshes, const int32_t *img_idx,
                                                       const int32_t *mesh_idx, const float *feat, const float *clu,
                                                       const float *C0, const float *theta0, const float *trans0,
@@ -1396,7 +1420,7 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
     const unsigned slot = (blockIdx.x * 0x9E3779B1u) >> 25;  // 0..127, well mixed
     for (unsigned i = 0; i < slot * stagger; ++i) __builtin_amdgcn_s_sleep(127);
   }
-  load_world_verts(P, L, M);
+  load_world_verts<BIG>(P, L, M);
   loss_constant(P, L, c);
   const bool lead = threadIdx.x == 0;
   if (lead) {
@@ -1417,7 +1441,7 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
   float last_loss = 0.f;
   u64 cov_total = 0;
   for (int t = 0; t < steps; ++t) {
-    eval_pose<D, PERSP, true, true>(P, L, M, f, c, none);
+    eval_pose<D, PERSP, true, true, false, false, BIG>(P, L, M, f, c, none);
 #ifdef NEMO_STAMPS
     const unsigned long long st_lead = (threadIdx.x == 0) ? __builtin_readcyclecounter() : 0ull;
 #endif
@@ -1480,7 +1504,7 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
 // coverage is recomputed from (R, T) (deterministic, identical to the forward),
 // grad_out plays the role of the feature map, and the block totals dL/dR, dL/dT
 // are written out for torch autograd to chain into campos / theta.
-template <int D, bool PERSP>
+template <int D, bool PERSP, bool BIG>
 __global__ __launch_bounds__(NT, 4) void interp_bwd_kernel(KParams P, const MeshDesc *meshes, const int32_t *mesh_idx,
                                                            const float *Rs, const float *Ts, const float *grad_out,
                                                            float *grad_R, float *grad_T) {
@@ -1490,9 +1514,9 @@ __global__ __launch_bounds__(NT, 4) void interp_bwd_kernel(KParams P, const Mesh
   const size_t hw = (size_t)P.h * P.w;
   if (threadIdx.x < 9) L.ust[U_R + threadIdx.x] = Rs[9 * n + threadIdx.x];
   if (threadIdx.x < 3) L.ust[U_T + threadIdx.x] = Ts[3 * n + threadIdx.x];
-  load_world_verts(P, L, M);
+  load_world_verts<BIG>(P, L, M);
   EmitOut none{nullptr, nullptr, nullptr};
-  eval_pose<D, PERSP, true, true, true>(P, L, M, grad_out + (size_t)n * hw * D, nullptr, none);
+  eval_pose<D, PERSP, true, true, true, false, BIG>(P, L, M, grad_out + (size_t)n * hw * D, nullptr, none);
   if (threadIdx.x < 9) grad_R[9 * n + threadIdx.x] = block_total(L, T_GR + threadIdx.x);
   if (threadIdx.x < 3) grad_T[3 * n + threadIdx.x] = block_total(L, T_GT + threadIdx.x);
 }
@@ -1587,6 +1611,8 @@ struct nemo_ctx {
   int32_t *d_gs_order, *d_gs_start, *d_gs_jobslot;
   float *d_gs_partial;
   size_t gs_jobs_cap, gs_partial_cap;
+  unsigned char *d_big;  // BIG-mesh table scratch
+  size_t big_cap;
   char err[512];
 };
 
@@ -1615,29 +1641,89 @@ static int plan_lds(nemo_ctx *ctx) {
   const nemo_config &c = ctx->cfg;
   const int vmax = ctx->vmax_seen > 0 ? ((ctx->vmax_seen + 63) & ~63) : 64;
   const int fmax = ctx->fmax_seen > 0 ? ((ctx->fmax_seen + 63) & ~63) : 64;
-  long avail = (long)LDS_BUDGET - (long)vmax * 16 - (long)fmax * 16 -
-               ((NW * RED_N + UST_N + c.raster_size + 12) * 4 + 128);
-  long cap = avail / (8 + 4);
-  if (cap > (long)c.win_h * c.win_w) cap = (long)c.win_h * c.win_w;
-  if ((long)c.win_h * c.win_w > 65536)
+  const long hw = (long)c.win_h * c.win_w;
+  if (hw > 65536)
     return fail(ctx, NEMO_ERR_UNSUPPORTED, "window %dx%d has more than 65536 pixels (16-bit pixel ids)", c.win_h, c.win_w);
-  {  // the z-buffer region also hosts the chunk partials and the phase A->B hand-off buffer
-    const long fixed = (long)(NW * CH * (12 + 16) + 64 * (2 * NW + 24) + 192);
+  const long misc = (NW * RED_N + UST_N + c.raster_size + 12) * 4 + 128;
+  const long fixed = (long)(NW * CH * (12 + 16) + 64 * (2 * NW + 24) + 192);  // score-phase scratch hosted by the z-buffer region
+  auto cap_for = [&](long avail) {
+    long cap = avail / (8 + 4);
+    if (cap > hw) cap = hw;
     if (avail - fixed < cap * 4 + 64 * (cap / CH)) cap = (avail - fixed) / 5;
+    return cap;
+  };
+  long cap = cap_for((long)LDS_BUDGET - (long)vmax * 16 - (long)fmax * 16 - misc);
+  int big = 0;
+  if (cap < c.win_w || cap < (hw < 2048 ? hw : 2048)) {
+    // the mesh tables would leave (almost) no z-buffer: keep them in global scratch instead (BIG kernels)
+    big = 1;
+    cap = cap_for((long)LDS_BUDGET - misc);
   }
   if (cap < c.win_w)
-    return fail(ctx, NEMO_ERR_UNSUPPORTED,
-                "mesh with %d vertices / %d faces and window width %d do not fit the %d-byte LDS plan",
-                ctx->vmax_seen, ctx->fmax_seen, c.win_w, LDS_BUDGET);
+    return fail(ctx, NEMO_ERR_UNSUPPORTED, "window width %d does not fit the %d-byte LDS plan", c.win_w, LDS_BUDGET);
   ctx->P.cap = (int)cap;
   ctx->P.vmax = vmax;
   ctx->P.fmax = fmax;
+  ctx->P.big = big;
+  ctx->P.big_stride = (unsigned)(((size_t)vmax * 16 + (size_t)fmax * 16 + 255) & ~(size_t)255);
   ctx->P.zb_bytes = (int)zb_region_bytes((int)cap);
   ctx->P.w_magic = (unsigned)(0x100000000ULL / (unsigned long long)c.win_w) + 1u;
-  ctx->lds = lds_bytes((int)cap, vmax, fmax, c.win_w, c.raster_size);
+  ctx->lds = lds_bytes((int)cap, big ? 0 : vmax, big ? 0 : fmax, c.win_w, c.raster_size);
   if (ctx->lds > (size_t)LDS_BUDGET) return fail(ctx, NEMO_ERR_UNSUPPORTED, "LDS plan %zu > budget", ctx->lds);
   return NEMO_OK;
 }
+
+// BIG meshes: one scratch slice (screen vertices, face ids, per-face fragment boxes) per workgroup of a launch.
+constexpr unsigned BIG_MAX_BLOCKS = 2048;  // launches with more workgroups are issued in slices of this many
+static int ensure_big_scratch(nemo_ctx *ctx, size_t nblocks) {
+  if (!ctx->P.big) return NEMO_OK;
+  if (nblocks > BIG_MAX_BLOCKS) nblocks = BIG_MAX_BLOCKS;
+  const size_t need = nblocks * (size_t)ctx->P.big_stride;
+  if (need > ctx->big_cap) {
+    hipFree(ctx->d_big);
+    ctx->d_big = nullptr;
+    ctx->big_cap = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_big, need));
+    ctx->big_cap = need;
+  }
+  ctx->P.big_scratch = (unsigned long long)(uintptr_t)ctx->d_big;
+  return NEMO_OK;
+}
+
+#define DISPATCH_DPB(kern, BIGV, grid, ...)                                                                       \
+  do {                                                                                                            \
+    const bool persp_ = ctx->P.persp != 0;                                                                        \
+    if (ctx->cfg.feat_dim == 128) {                                                                               \
+      if (persp_) hipLaunchKernelGGL((kern<128, true, BIGV>), grid, dim3(NT), ctx->lds, (hipStream_t)stream, __VA_ARGS__); \
+      else hipLaunchKernelGGL((kern<128, false, BIGV>), grid, dim3(NT), ctx->lds, (hipStream_t)stream, __VA_ARGS__);      \
+    } else {                                                                                                      \
+      if (persp_) hipLaunchKernelGGL((kern<256, true, BIGV>), grid, dim3(NT), ctx->lds, (hipStream_t)stream, __VA_ARGS__); \
+      else hipLaunchKernelGGL((kern<256, false, BIGV>), grid, dim3(NT), ctx->lds, (hipStream_t)stream, __VA_ARGS__);      \
+    }                                                                                                             \
+  } while (0)
+// One workgroup per job; BIG meshes need a scratch slice per workgroup of the launch.
+#define DISPATCH_DP(kern, grid, ...)                                                            \
+  do {                                                                                          \
+    if (ctx->P.big) {                                                                           \
+      if ((grid).x > BIG_MAX_BLOCKS)                                                            \
+        return fail(ctx, NEMO_ERR_UNSUPPORTED, "%u jobs in one call with a large mesh (limit %u)", (grid).x, BIG_MAX_BLOCKS); \
+      int rc_ = ensure_big_scratch(ctx, (grid).x);                                              \
+      if (rc_ != NEMO_OK) return rc_;                                                           \
+      DISPATCH_DPB(kern, true, grid, __VA_ARGS__);                                              \
+    } else {                                                                                    \
+      DISPATCH_DPB(kern, false, grid, __VA_ARGS__);                                             \
+    }                                                                                           \
+  } while (0)
+#define LAUNCH_PB(kern, grid, st, ...)                                                          \
+  do {                                                                                          \
+    if (ctx->P.big) {                                                                           \
+      if (ctx->P.persp) hipLaunchKernelGGL((kern<true, true>), grid, dim3(NT), ctx->lds, st, __VA_ARGS__);   \
+      else hipLaunchKernelGGL((kern<false, true>), grid, dim3(NT), ctx->lds, st, __VA_ARGS__);  \
+    } else {                                                                                    \
+      if (ctx->P.persp) hipLaunchKernelGGL((kern<true, false>), grid, dim3(NT), ctx->lds, st, __VA_ARGS__);  \
+      else hipLaunchKernelGGL((kern<false, false>), grid, dim3(NT), ctx->lds, st, __VA_ARGS__); \
+    }                                                                                           \
+  } while (0)
 
 extern "C" {
 
@@ -1680,16 +1766,18 @@ int nemo_ctx_create(const nemo_config *cfg, nemo_ctx **out) {
   // opt in to > 64 KiB dynamic LDS for every pose kernel instantiation
   const int maxlds = LDS_BUDGET;
 #define SET_LDS(k) hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds)
-  SET_LDS((raster_kernel<false>)); SET_LDS((raster_kernel<true>));
-  SET_LDS((score_kernel<128, false>)); SET_LDS((score_kernel<128, true>));
-  SET_LDS((score_kernel<256, false>)); SET_LDS((score_kernel<256, true>));
-  SET_LDS((grid_kernel<128, false>)); SET_LDS((grid_kernel<128, true>));
-  SET_LDS((grid_kernel<256, false>)); SET_LDS((grid_kernel<256, true>));
-  SET_LDS((prerender_kernel<false>)); SET_LDS((prerender_kernel<true>));
-  SET_LDS((solve_kernel<128, false>)); SET_LDS((solve_kernel<128, true>));
-  SET_LDS((solve_kernel<256, false>)); SET_LDS((solve_kernel<256, true>));
-  SET_LDS((interp_bwd_kernel<128, false>)); SET_LDS((interp_bwd_kernel<128, true>));
-  SET_LDS((interp_bwd_kernel<256, false>)); SET_LDS((interp_bwd_kernel<256, true>));
+#define SET_LDS_B(k, ...) SET_LDS((k<__VA_ARGS__, false>)); SET_LDS((k<__VA_ARGS__, true>))
+  SET_LDS_B(raster_kernel, false); SET_LDS_B(raster_kernel, true);
+  SET_LDS_B(prerender_kernel, false); SET_LDS_B(prerender_kernel, true);
+  SET_LDS_B(score_kernel, 128, false); SET_LDS_B(score_kernel, 128, true);
+  SET_LDS_B(score_kernel, 256, false); SET_LDS_B(score_kernel, 256, true);
+  SET_LDS_B(grid_kernel, 128, false); SET_LDS_B(grid_kernel, 128, true);
+  SET_LDS_B(grid_kernel, 256, false); SET_LDS_B(grid_kernel, 256, true);
+  SET_LDS_B(solve_kernel, 128, false); SET_LDS_B(solve_kernel, 128, true);
+  SET_LDS_B(solve_kernel, 256, false); SET_LDS_B(solve_kernel, 256, true);
+  SET_LDS_B(interp_bwd_kernel, 128, false); SET_LDS_B(interp_bwd_kernel, 128, true);
+  SET_LDS_B(interp_bwd_kernel, 256, false); SET_LDS_B(interp_bwd_kernel, 256, true);
+#undef SET_LDS_B
 #undef SET_LDS
   *out = ctx;
   return NEMO_OK;
@@ -1702,7 +1790,7 @@ int nemo_ctx_destroy(nemo_ctx *ctx) {
   hipFree(ctx->d_adam);
   hipFree(ctx->d_pre_slot); hipFree(ctx->d_pre_cnt); hipFree(ctx->d_pre_pairs); hipFree(ctx->d_pre_list);
   hipFree(ctx->d_pre_maps); hipFree(ctx->d_gs_order); hipFree(ctx->d_gs_start); hipFree(ctx->d_gs_jobslot);
-  hipFree(ctx->d_gs_partial);
+  hipFree(ctx->d_gs_partial); hipFree(ctx->d_big);
   delete ctx;
   return NEMO_OK;
 }
@@ -1759,12 +1847,11 @@ int nemo_rasterize(nemo_ctx *ctx, const int32_t *d_mesh_idx, const float *d_R, c
   if (rc) return rc > 0 ? NEMO_OK : rc;
   if (!d_R || !d_T || !d_pix_to_face || !d_bary) return fail(ctx, NEMO_ERR_ARG, "nemo_rasterize: null buffer");
   if (N == 0) return NEMO_OK;
-  if (ctx->P.persp)
-    hipLaunchKernelGGL((raster_kernel<true>), dim3(N), dim3(NT), ctx->lds, (hipStream_t)stream, ctx->P, ctx->d_meshes,
-                       d_mesh_idx, d_R, d_T, d_pix_to_face, d_bary, d_zbuf);
-  else
-    hipLaunchKernelGGL((raster_kernel<false>), dim3(N), dim3(NT), ctx->lds, (hipStream_t)stream, ctx->P, ctx->d_meshes,
-                       d_mesh_idx, d_R, d_T, d_pix_to_face, d_bary, d_zbuf);
+  if (ctx->P.big && (unsigned)N > BIG_MAX_BLOCKS)
+    return fail(ctx, NEMO_ERR_UNSUPPORTED, "nemo_rasterize: %d jobs in one call with a large mesh (limit %u)", N, BIG_MAX_BLOCKS);
+  if ((rc = ensure_big_scratch(ctx, (size_t)N)) != NEMO_OK) return rc;
+  LAUNCH_PB(raster_kernel, dim3(N), (hipStream_t)stream, ctx->P, ctx->d_meshes, d_mesh_idx, d_R, d_T, d_pix_to_face, d_bary,
+            d_zbuf);
   HIP_TRY(ctx, hipGetLastError());
   return NEMO_OK;
 }
@@ -1782,18 +1869,6 @@ int nemo_interpolate(nemo_ctx *ctx, const int32_t *d_mesh_idx, const int32_t *d_
   HIP_TRY(ctx, hipGetLastError());
   return NEMO_OK;
 }
-
-#define DISPATCH_DP(kern, grid, ...)                                                                              \
-  do {                                                                                                            \
-    const bool persp_ = ctx->P.persp != 0;                                                                        \
-    if (ctx->cfg.feat_dim == 128) {                                                                               \
-      if (persp_) hipLaunchKernelGGL((kern<128, true>), grid, dim3(NT), ctx->lds, (hipStream_t)stream, __VA_ARGS__); \
-      else hipLaunchKernelGGL((kern<128, false>), grid, dim3(NT), ctx->lds, (hipStream_t)stream, __VA_ARGS__);      \
-    } else {                                                                                                      \
-      if (persp_) hipLaunchKernelGGL((kern<256, true>), grid, dim3(NT), ctx->lds, (hipStream_t)stream, __VA_ARGS__); \
-      else hipLaunchKernelGGL((kern<256, false>), grid, dim3(NT), ctx->lds, (hipStream_t)stream, __VA_ARGS__);      \
-    }                                                                                                             \
-  } while (0)
 
 int nemo_score_fwd_bwd(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t *d_mesh_idx,
                        const float *d_feat, const float *d_clu, const float *d_C, const float *d_theta, float *d_loss,
@@ -1862,8 +1937,18 @@ int nemo_grid_search(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const i
                        ctx->d_gs_jobslot, d_clu, ctx->d_gs_partial, ctx->d_pre_cnt, d_losses, ctx->d_counter, con);
     HIP_TRY(ctx, hipGetLastError());
   }
-  DISPATCH_DP(grid_kernel, dim3((unsigned)blocks), ctx->P, ctx->d_meshes, N, d_img_idx, d_mesh_idx, d_grid_idx, d_feat,
-              d_clu, d_grid_C, d_grid_theta, G, d_losses, ctx->d_counter, pre, mfma ? 1 : 0);
+  if (ctx->P.big) {
+    int rc_ = ensure_big_scratch(ctx, (size_t)blocks);
+    if (rc_ != NEMO_OK) return rc_;
+    for (long long b0 = 0; b0 < blocks; b0 += BIG_MAX_BLOCKS) {
+      const unsigned nb = (unsigned)(blocks - b0 < (long long)BIG_MAX_BLOCKS ? blocks - b0 : (long long)BIG_MAX_BLOCKS);
+      DISPATCH_DPB(grid_kernel, true, dim3(nb), ctx->P, ctx->d_meshes, N, d_img_idx, d_mesh_idx, d_grid_idx, d_feat, d_clu,
+                   d_grid_C, d_grid_theta, G, d_losses, ctx->d_counter, pre, mfma ? 1 : 0, (unsigned)b0);
+    }
+  } else {
+    DISPATCH_DPB(grid_kernel, false, dim3((unsigned)blocks), ctx->P, ctx->d_meshes, N, d_img_idx, d_mesh_idx, d_grid_idx, d_feat,
+                 d_clu, d_grid_C, d_grid_theta, G, d_losses, ctx->d_counter, pre, mfma ? 1 : 0, 0u);
+  }
   HIP_TRY(ctx, hipGetLastError());
   hipLaunchKernelGGL(grid_argmin_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, N, G, d_losses, d_grid_idx,
                      d_grid_C, d_grid_theta, d_C0, d_theta0, d_best);
@@ -1900,14 +1985,14 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
   HIP_TRY(ctx, hipMemcpy(ctx->d_pre_pairs, h_pair_mesh, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(ctx->d_pre_pairs + n_pairs, h_pair_grid, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice));
   const dim3 grid((unsigned)(n_pairs * G));
-  if (ctx->P.persp)
-    hipLaunchKernelGGL((prerender_kernel<true>), grid, dim3(NT), ctx->lds, (hipStream_t)stream, ctx->P, ctx->d_meshes,
-                       ctx->d_pre_pairs, ctx->d_pre_pairs + n_pairs, d_grid_C, d_grid_theta, G, ctx->d_pre_list,
-                       ctx->d_pre_cnt, stride);
-  else
-    hipLaunchKernelGGL((prerender_kernel<false>), grid, dim3(NT), ctx->lds, (hipStream_t)stream, ctx->P, ctx->d_meshes,
-                       ctx->d_pre_pairs, ctx->d_pre_pairs + n_pairs, d_grid_C, d_grid_theta, G, ctx->d_pre_list,
-                       ctx->d_pre_cnt, stride);
+  if (ctx->P.big && grid.x > BIG_MAX_BLOCKS)
+    return fail(ctx, NEMO_ERR_UNSUPPORTED, "nemo_grid_prerender: %u (pair, pose) renders with a large mesh (limit %u per call)", grid.x, BIG_MAX_BLOCKS);
+  {
+    int rc_ = ensure_big_scratch(ctx, grid.x);
+    if (rc_ != NEMO_OK) return rc_;
+  }
+  LAUNCH_PB(prerender_kernel, grid, (hipStream_t)stream, ctx->P, ctx->d_meshes, ctx->d_pre_pairs, ctx->d_pre_pairs + n_pairs,
+            d_grid_C, d_grid_theta, G, ctx->d_pre_list, ctx->d_pre_cnt, stride);
   HIP_TRY(ctx, hipGetLastError());
   ctx->pre_gridC = d_grid_C; ctx->pre_gridT = d_grid_theta;
   ctx->pre_G = G; ctx->pre_pairs = n_pairs;
@@ -1944,12 +2029,7 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
                          d_grid_C, d_grid_theta, d_C, d_t);
       hipLaunchKernelGGL(campos_kernel, dim3((unsigned)((jobs + 63) / 64)), dim3(64), 0, st, d_C, d_t, (const float *)nullptr,
                          (int)jobs, d_R, d_T);
-      if (ctx->P.persp)
-        hipLaunchKernelGGL((raster_kernel<true>), dim3((unsigned)jobs), dim3(NT), ctx->lds, st, ctx->P, ctx->d_meshes, d_mesh,
-                           d_R, d_T, d_p2f, d_bary, (float *)nullptr);
-      else
-        hipLaunchKernelGGL((raster_kernel<false>), dim3((unsigned)jobs), dim3(NT), ctx->lds, st, ctx->P, ctx->d_meshes, d_mesh,
-                           d_R, d_T, d_p2f, d_bary, (float *)nullptr);
+      LAUNCH_PB(raster_kernel, dim3((unsigned)jobs), st, ctx->P, ctx->d_meshes, d_mesh, d_R, d_T, d_p2f, d_bary, (float *)nullptr);
       const size_t npix = jobs * stride, threads = npix * (D / 4);
       hipLaunchKernelGGL(interpolate_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (int)D, npix, stride,
                          ctx->d_meshes, d_mesh, d_p2f, d_bary, ctx->d_pre_maps);

@@ -581,3 +581,45 @@ def test_dense_pose_grid_search(oracle):
         bo, lo = oracle.grid_search(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[i], sc.clus[i], gC, gth)
         assert np.abs(losses[i] - lo).max() <= REL * np.abs(lo).max()
         assert best[i] == bo
+
+
+def test_large_mesh_256d_double_resolution(oracle):
+    """BASELINE config 5 shape: subdivided cuboid (10 466 vertices, 19 872 faces), 256-d features, 160x200
+    window of a 200x200 raster, clutter loss.  The mesh tables do not fit the LDS, so the kernels run in their
+    BIG form (tables in a global scratch slice per workgroup, z-buffer in row bands).  Bit-exact rasterizer,
+    loss / gradient parity, and teacher-forced steps of the fused solve."""
+    sc = make_scene('car', (1280, 1600), 10000, D=256, n_img=1, seed=5)
+    assert sc.verts.shape[0] > 10000 and (sc.cfg.S, sc.cfg.h, sc.cfg.w) == (200, 160, 200)
+    eng = _engine(sc)
+    rng = np.random.default_rng(6)
+    az, el, th_gt, d = sc.gt[0]
+    C = np.stack([syn.spherical_to_campos(d * 1.02, el + 0.03, az - 0.04), syn.spherical_to_campos(d * 0.9, el - 0.1, az + 0.5)])
+    th = np.array([th_gt + 0.02, th_gt - 0.2], np.float32)
+    R, T = eng.campos_to_R_T(_dev(C), _dev(th))
+    p2f, bary = eng.rasterize(R, T)[:2]
+    loss, grad, ncov = eng.score_fwd_bwd(_dev(sc.feats), _dev(sc.clus), _dev(C), _dev(th), img_idx=_dev([0, 0], torch.int32))
+    for i in range(2):
+        e = oracle.evaluate(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[0], sc.clus[0], C[i], th[i], want_maps=True)
+        assert np.array_equal(p2f[i].cpu().numpy().reshape(-1), e['pix_to_face'].reshape(-1))
+        cov = e['pix_to_face'].reshape(-1) >= 0
+        assert np.array_equal(bary[i].cpu().numpy().reshape(-1, 3)[cov], e['bary'].reshape(-1, 3)[cov])
+        assert int(ncov[i]) == e['ncov'] and e['ncov'] > 5000
+        assert abs(loss[i].item() - e['loss']) <= REL * abs(e['loss'])
+        assert _relerr(grad[i].cpu().numpy(), np.r_[e['gC'], e['gtheta']]) <= REL
+    eng.set_schedule(12)
+    pose, _, trace = eng.solve(_dev(sc.feats), _dev(sc.clus), _dev(C[:1]), _dev(th[:1]), want_trace=True)
+    trace = trace.cpu().numpy()[0]
+    for t in (0, 5, 11):
+        e = oracle.evaluate(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[0], sc.clus[0], trace[t, 0:3], trace[t, 3])
+        assert abs(trace[t, 4] - e['loss']) <= REL * abs(e['loss'])
+        assert _relerr(trace[t, 5:9], np.r_[e['gC'], e['gtheta']]) <= REL
+    assert trace[11, 4] < trace[0, 4]
+    # grid search over a few poses (on the fly, then pre-rendered) agrees with the oracle
+    gC, gth = syn.pose_grid(sc.distance, n_azim=4, n_elev=2, n_theta=1)
+    dC, dth = _dev(gC[None]), _dev(gth[None])
+    _, _, b0, l0 = eng.grid_search(_dev(sc.feats), _dev(sc.clus), dC, dth)
+    bo, lo = oracle.grid_search(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[0], sc.clus[0], gC, gth)
+    assert np.abs(l0[0].cpu().numpy() - lo).max() <= REL * np.abs(lo).max() and int(b0[0]) == bo
+    eng.grid_prerender(dC, dth, [(0, 0)])
+    _, _, b1, l1 = eng.grid_search(_dev(sc.feats), _dev(sc.clus), dC, dth)
+    assert np.abs(l1[0].cpu().numpy() - lo).max() <= REL * np.abs(lo).max() and int(b1[0]) == bo
