@@ -53,6 +53,7 @@ class PoseEngine:
         self.h, self.w = int(map_shape[0]), int(map_shape[1])
         self.D = int(feat_dim)
         self.ndc_scale = ndc_scale(fov)
+        self.clutter = bool(clutter)
         r0, c0 = (-1, -1) if crop_origin is None else crop_origin
         self.cfg = _lib.NemoConfig(self.S, self.h, self.w, r0, c0, self.D, self.ndc_scale,
                                    int(perspective_correct), int(clutter), float(k_eps))

@@ -623,3 +623,24 @@ def test_large_mesh_256d_double_resolution(oracle):
     eng.grid_prerender(dC, dth, [(0, 0)])
     _, _, b1, l1 = eng.grid_search(_dev(sc.feats), _dev(sc.clus), dC, dth)
     assert np.abs(l1[0].cpu().numpy() - lo).max() <= REL * np.abs(lo).max() and int(b1[0]) == bo
+
+
+def test_loss_landscape_scans(oracle):
+    """tools/PlotLossLandscape.py:111-169 as one batched launch: every scanned pose against the oracle's
+    clutter-free loss, and the scans bottom out at the annotated pose."""
+    from nemo_amd import landscape
+    sc = make_scene(n_img=2, clutter=False, seed=51)
+    eng = _engine(sc)
+    annos = [(az, el, th) for az, el, th, _ in sc.gt]
+    shifts = dict(az_shifts=np.linspace(-3.14, 3.14, 13), el_shifts=np.linspace(-0.6, 0.6, 7),
+                  th_shifts=np.linspace(-0.6, 0.6, 7), d_shifts=np.linspace(-1, 1, 5))
+    scans = landscape.scan_losses(eng, _dev(sc.feats), annos, sc.distance, **shifts)
+    assert scans['azimuth'].shape == (2, 13) and scans['distance'].shape == (2, 5)
+    for i, (az, el, th) in enumerate(annos):
+        C, t, sl = landscape.scan_poses(az, el, th, sc.distance, **shifts)
+        got = np.concatenate([scans[k][i] for k in ('azimuth', 'elevation', 'theta', 'distance')])
+        for k in range(0, len(t), 3):
+            e = oracle.evaluate(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[i], None, C[k], t[k])
+            assert abs(got[k] - e['loss']) <= REL * abs(e['loss'])
+        for k in ('elevation', 'theta'):
+            assert int(np.argmin(scans[k][i])) == len(scans[k][i]) // 2   # zero shift is the minimum
