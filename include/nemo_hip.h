@@ -105,6 +105,15 @@ int nemo_interpolate_backward(nemo_ctx *ctx, const int32_t *d_mesh_idx, const fl
 int nemo_clutter_score(nemo_ctx *ctx, const float *d_feat, int32_t n_img, const float *d_cbank,
                        int32_t K, float *d_out, void *stream);
 
+/* Backbone tail + clutter score in one pass: NetE2E.forward_test after the backbone
+ * (code/models/KeypointRepresentationNet.py:217-223) = 1x1 convolution with out_layer.weight f32[D][C] (no bias)
+ * + F.normalize over channels (eps 1e-12), fused with the clutter score of code/MeshPoseSolveAll.py:220.
+ * d_x f32[N][C][h*w] (the backbone's NCHW output at the feature-map resolution); d_feat f32[N][h][w][D] is written
+ * pixel-major, ready for the calls below; d_clu f32[N][h][w] = max_k <d_cbank[k], feat> or NULL.  The contraction
+ * runs on the fp32 matrix cores; D*C*4 bytes of weights must fit 128 KiB of LDS (C = 256 at D = 128). */
+int nemo_feature_head(nemo_ctx *ctx, const float *d_x, int32_t N, int32_t C, const float *d_weight,
+                      const float *d_cbank, int32_t K, float *d_feat, float *d_clu, void *stream);
+
 /* One render-and-compare evaluation per job at given poses: object score
  * (:237), loss (:238), and dL/dC, dL/dtheta as loss.backward() (:240) would
  * leave them in C.grad / theta.grad.  d_loss f32[N], d_grad f32[N][4]

@@ -1369,6 +1369,98 @@ __global__ __launch_bounds__(256) void grid_finish_kernel(int hw, float inv_hw, 
   if (counter && cov) atomicAdd(counter, cov);
 }
 
+// ---------------------------------------------------------------- backbone tail
+// NetE2E.forward_test after the backbone (code/models/KeypointRepresentationNet.py:217-223): the 1x1 convolution
+// with out_layer.weight [D][C] (no bias), F.normalize over the D channels (eps 1e-12), and -- fused -- the clutter
+// score of code/MeshPoseSolveAll.py:220.  Input x is the backbone's [N][C][h*w] map; the output is written
+// directly in the solver's pixel-major layout [N][h*w][D].
+// out[d, p] = sum_c W[d, c] x[c, p] runs on v_mfma_f32_32x32x2_f32: A = 32 output channels (D/32 tiles kept in
+// accumulators), B = 32 consecutive pixels of one image (coalesced dword loads per channel), the whole weight
+// matrix staged once per workgroup in LDS in the order the lanes consume it.  Workgroups are persistent.
+template <int D>
+__global__ __launch_bounds__(256) void feature_head_kernel(const float *__restrict__ x, int N, int C, int hw,
+                                                           const float *__restrict__ weight,
+                                                           const float *__restrict__ cbank, int K,
+                                                           float *__restrict__ feat, float *__restrict__ clu) {
+  constexpr int T = D / 32;           // output-channel tiles
+  extern __shared__ float wl[];       // [C/2][2][32][T]: (k-step, half, row in tile, tile)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, half = lane >> 5;
+  for (int k = tid; k < D * C; k += 256) {
+    const int d = k / C, c = k - d * C;
+    wl[(((c >> 1) * 2 + (c & 1)) * 32 + (d & 31)) * T + (d >> 5)] = weight[k];
+  }
+  __syncthreads();
+  const int tiles_per_img = (hw + 31) / 32;
+  const long long total = (long long)N * tiles_per_img;
+  // The LDS-resident weights leave room for one workgroup (one wave per SIMD) per CU, so each wave has the
+  // whole register file: the B operand of a tile (one float per k-step) is fetched a full tile ahead.
+  constexpr int KS = 128;  // k-steps held in registers (C <= 256)
+  float bcur[KS], bnxt[KS];
+  auto fetch = [&](long long tile, float (&b)[KS]) {
+    const int n = (int)(tile / tiles_per_img), p0 = (int)(tile - (long long)n * tiles_per_img) * 32;
+    const float *xp = x + ((size_t)n * C + half) * hw + min(p0 + i, hw - 1);  // channel 2s + half of the lane's pixel
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) b[s2] = s2 < C / 2 ? __builtin_nontemporal_load(xp + (size_t)(2 * s2) * hw) : 0.0f;
+  };
+  long long tile = (long long)blockIdx.x * 4 + wave;
+  const long long stride = (long long)gridDim.x * 4;
+  if (tile < total) fetch(tile, bcur);
+  for (; tile < total; tile += stride) {
+    const int n = (int)(tile / tiles_per_img), p0 = (int)(tile - (long long)n * tiles_per_img) * 32;
+    const int p = min(p0 + i, hw - 1);
+    const bool pok = p0 + i < hw;
+    if (tile + stride < total) fetch(tile + stride, bnxt);
+    f16v acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) {
+      if (s2 < C / 2) {
+        const float *wp = wl + ((s2 * 2 + half) * 32 + i) * T;
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[t], bcur[s2], acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) bcur[s2] = bnxt[s2];
+    // lane (pixel j = i, half) holds channels d = 32 t + 8 q + 4 half + c, q, c = 0..3  (acc[t][4 q + c])
+    float n2 = 0.0f;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) n2 = fmaf(acc[t][r], acc[t][r], n2);
+    n2 += __shfl_xor(n2, 32);
+    const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);  // F.normalize(p=2, dim=1, eps=1e-12)
+    float *op = feat + ((size_t)n * hw + p) * D + 4 * half;
+    float best = -INFINITY;
+    for (int k = 0; k < (clu ? K : 0); ++k) {
+      const float *ck = cbank + (size_t)k * D + 4 * half;
+      float dsum = 0.0f;
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f4 cv = *(const f4 *)(ck + 32 * t + 8 * q);
+          dsum = fmaf(acc[t][4 * q] * inv, cv.x, dsum); dsum = fmaf(acc[t][4 * q + 1] * inv, cv.y, dsum);
+          dsum = fmaf(acc[t][4 * q + 2] * inv, cv.z, dsum); dsum = fmaf(acc[t][4 * q + 3] * inv, cv.w, dsum);
+        }
+      dsum += __shfl_xor(dsum, 32);
+      best = fmaxf(best, dsum);
+    }
+    if (pok) {
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *(f4 *)(op + 32 * t + 8 * q) = f4{acc[t][4 * q] * inv, acc[t][4 * q + 1] * inv, acc[t][4 * q + 2] * inv, acc[t][4 * q + 3] * inv};
+      if (clu && half == 0) clu[(size_t)n * hw + p] = best;
+    }
+  }
+}
+
 // argmin over the grid losses (first minimum, torch.min semantics at
 // code/MeshPoseSolveAll.py:97) -> C0, theta0.
 __global__ void grid_argmin_kernel(int N, int G, const float *losses, const int32_t *grid_idx, const float *gridC,
@@ -2102,6 +2194,36 @@ int nemo_clutter_score(nemo_ctx *ctx, const float *d_feat, int32_t n_img, const 
     hipLaunchKernelGGL((clutter_kernel<128>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_feat, npix, d_cbank, K, d_out);
   else
     hipLaunchKernelGGL((clutter_kernel<256>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_feat, npix, d_cbank, K, d_out);
+  HIP_TRY(ctx, hipGetLastError());
+  return NEMO_OK;
+}
+
+int nemo_feature_head(nemo_ctx *ctx, const float *d_x, int32_t N, int32_t C, const float *d_weight, const float *d_cbank,
+                      int32_t K, float *d_feat, float *d_clu, void *stream) {
+  if (!ctx) return fail(nullptr, NEMO_ERR_ARG, "nemo_feature_head: null ctx");
+  if (N < 0 || C <= 0) return fail(ctx, NEMO_ERR_ARG, "nemo_feature_head: bad argument");
+  if (N == 0) return NEMO_OK;
+  if (!d_x || !d_weight || !d_feat) return fail(ctx, NEMO_ERR_ARG, "nemo_feature_head: null buffer");
+  if (d_clu && (!d_cbank || K <= 0)) return fail(ctx, NEMO_ERR_ARG, "nemo_feature_head: clutter output needs a clutter bank");
+  const int D = ctx->cfg.feat_dim, hw = ctx->cfg.win_h * ctx->cfg.win_w;
+  const size_t lds = (size_t)D * C * sizeof(float);
+  if ((C & 1) || lds > 128 * 1024)
+    return fail(ctx, NEMO_ERR_UNSUPPORTED, "nemo_feature_head: C = %d (even, D*C*4 <= 128 KiB: the weights are LDS-resident)", C);
+  int n_cu = 256;
+  hipDeviceProp_t prop;
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+  const long long tiles = (long long)N * ((hw + 31) / 32);
+  const unsigned blocks = (unsigned)(tiles / 4 < n_cu ? (tiles + 3) / 4 : n_cu);
+  if (D == 128) {
+    HIP_TRY(ctx, hipFuncSetAttribute((const void *)feature_head_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((feature_head_kernel<128>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, d_x, N, C, hw, d_weight,
+                       d_cbank, K, d_feat, d_clu);
+  } else {
+    HIP_TRY(ctx, hipFuncSetAttribute((const void *)feature_head_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((feature_head_kernel<256>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, d_x, N, C, hw, d_weight,
+                       d_cbank, K, d_feat, d_clu);
+  }
   HIP_TRY(ctx, hipGetLastError());
   return NEMO_OK;
 }

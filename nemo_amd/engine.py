@@ -162,6 +162,22 @@ class PoseEngine:
                                                          _ptr(out), self._stream()), 'nemo_clutter_score')
         return out
 
+    def feature_head(self, x, weight, cbank=None):
+        """Backbone tail (KeypointRepresentationNet.py:217-223) fused with the clutter score: x [N,C,h,w] f32 ->
+        (features [N,h,w,D] pixel-major, clutter score [N,h,w] or None)."""
+        x, weight = self._f32(x, 'x'), self._f32(weight, 'weight')
+        N, Cin = x.shape[0], x.shape[1]
+        if tuple(x.shape[2:]) != (self.h, self.w) or tuple(weight.shape) != (self.D, Cin):
+            raise ValueError('feature_head: x %s / weight %s do not match the %dx%d map and D=%d' %
+                             (tuple(x.shape), tuple(weight.shape), self.h, self.w, self.D))
+        feat = self._empty((N, self.h, self.w, self.D))
+        cb = self._f32(cbank, 'cbank') if cbank is not None else None
+        clu = self._empty((N, self.h, self.w)) if cb is not None else None
+        _lib.check(self.ctx, self.lib.nemo_feature_head(self.ctx, _ptr(x), N, Cin, _ptr(weight), _ptr(cb),
+                                                        cb.shape[0] if cb is not None else 0, _ptr(feat), _ptr(clu),
+                                                        self._stream()), 'nemo_feature_head')
+        return feat, clu
+
     def score_fwd_bwd(self, feat, clu, C_, theta, img_idx=None, mesh_idx=None, want_grad=True):
         C_, theta = self._f32(C_, 'C'), self._f32(theta, 'theta')
         N = C_.shape[0]

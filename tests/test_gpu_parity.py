@@ -644,3 +644,29 @@ def test_loss_landscape_scans(oracle):
             assert abs(got[k] - e['loss']) <= REL * abs(e['loss'])
         for k in ('elevation', 'theta'):
             assert int(np.argmin(scans[k][i])) == len(scans[k][i]) // 2   # zero shift is the minimum
+
+
+@pytest.mark.parametrize('D,Cin', [(128, 256), (256, 64)])
+def test_feature_head_matches_torch(D, Cin):
+    """Backbone tail (code/models/KeypointRepresentationNet.py:217-223: 1x1 conv with out_layer.weight, then
+    F.normalize over channels) fused with the clutter score (code/MeshPoseSolveAll.py:220), against the same ops
+    in torch fp32.  Ragged pixel count (h*w not a multiple of 32), K = 1 and K = 3 clutter vectors."""
+    import torch.nn.functional as F
+    from nemo_amd.engine import PoseEngine
+    h, w, N = 13, 19, 3
+    eng = PoseEngine(24, (h, w), D)
+    g = torch.Generator(device='cpu').manual_seed(5)
+    x = torch.randn(N, Cin, h, w, generator=g).cuda()
+    W = (torch.randn(D, Cin, generator=g) / Cin ** 0.5).cuda()
+    for K in (1, 3):
+        cb = F.normalize(torch.randn(K, D, generator=g), dim=1).cuda()
+        feat, clu = eng.feature_head(x, W, cb)
+        ref = F.normalize(F.conv2d(x, W[:, :, None, None]), p=2, dim=1)                  # [N,D,h,w]
+        ref_clu = F.conv2d(ref, cb[:, :, None, None]).max(dim=1)[0]                      # [N,h,w]
+        assert feat.shape == (N, h, w, D) and clu.shape == (N, h, w)
+        assert (feat - ref.permute(0, 2, 3, 1)).abs().max().item() <= 2e-6
+        assert (clu - ref_clu).abs().max().item() <= 5e-6
+    feat2, none = eng.feature_head(x, W)
+    assert none is None and torch.equal(feat2, feat)
+    # the fused clutter score equals the standalone kernel's on the produced features
+    assert (eng.clutter_score(feat, cb) - clu).abs().max().item() <= 2e-6
