@@ -671,19 +671,19 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
               i0 = n0;
               const gf4p B = (gf4p)(bbytes + ((uint32_t)n0 * (uint32_t)(D * 4) + gl16));
 #pragma unroll
-              for (int k = 0; k < KIT; ++k) y0[k] = (GRAD && (NEMO_ABL & 2)) ? f4{(float)n0, 1.f, 2.f, 3.f} : B[LPP * k];
+              for (int k = 0; k < KIT; ++k) y0[k] = (GRAD && (NEMO_ABL & 2)) ? f4{(float)n0, 1.f, 2.f, 3.f} : (GRAD && (NEMO_ABL & 16)) ? ((const f4 *)L.list)[((n0 & 31) * (D / 4) + gl + LPP * k) & 2047] : B[LPP * k];
             }
             if (n1 != i1) {
               i1 = n1;
               const gf4p B = (gf4p)(bbytes + ((uint32_t)n1 * (uint32_t)(D * 4) + gl16));
 #pragma unroll
-              for (int k = 0; k < KIT; ++k) y1[k] = (GRAD && (NEMO_ABL & 2)) ? f4{(float)n1, 1.f, 2.f, 3.f} : B[LPP * k];
+              for (int k = 0; k < KIT; ++k) y1[k] = (GRAD && (NEMO_ABL & 2)) ? f4{(float)n1, 1.f, 2.f, 3.f} : (GRAD && (NEMO_ABL & 16)) ? ((const f4 *)L.list)[((n1 & 31) * (D / 4) + gl + LPP * k) & 2047] : B[LPP * k];
             }
             if (n2 != i2) {
               i2 = n2;
               const gf4p B = (gf4p)(bbytes + ((uint32_t)n2 * (uint32_t)(D * 4) + gl16));
 #pragma unroll
-              for (int k = 0; k < KIT; ++k) y2[k] = (GRAD && (NEMO_ABL & 2)) ? f4{(float)n2, 1.f, 2.f, 3.f} : B[LPP * k];
+              for (int k = 0; k < KIT; ++k) y2[k] = (GRAD && (NEMO_ABL & 2)) ? f4{(float)n2, 1.f, 2.f, 3.f} : (GRAD && (NEMO_ABL & 16)) ? ((const f4 *)L.list)[((n2 & 31) * (D / 4) + gl + LPP * k) & 2047] : B[LPP * k];
             }
             // ... 2nd: the next entry's feature row, which stays in flight (vmcnt is in order)
             {
