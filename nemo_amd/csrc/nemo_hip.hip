@@ -28,6 +28,7 @@
 #include <string.h>
 
 #include "nemo_hip.h"
+#include "fastdiv.h"
 
 namespace {
 
@@ -54,6 +55,8 @@ constexpr int LDS_BUDGET = 160 * 1024 / (1024 / NT) - (NT < 1024 ? 512 : 0);  //
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
 typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u2v __attribute__((ext_vector_type(2)));
 // Pointers that come out of the mesh table are global memory; saying so lets the
 // compiler emit global_load (vmcnt only) instead of flat_load.
 #define GAS __attribute__((address_space(1)))
@@ -333,16 +336,19 @@ __device__ __forceinline__ float wave_max(float v) {
 // Diagnostic build only (-DNEMO_STAMPS): wave 0 / lane 0 of every workgroup adds the
 // cycles it spent per phase (barrier waits included) into g_stamps; the shipped
 // library contains none of this.
+#ifndef NEMO_RABL
+#define NEMO_RABL 0  // rasteriser ablations (diagnostic builds): 1 = no candidate loop, 2 = candidates never accepted
+#endif
 #ifndef NEMO_ABL
 #define NEMO_ABL 0  // diagnostic builds (solve kernel only): 1 = no feature-row loads, 2 = no bank-row loads, 4 = no phase A loop
 #endif
 #ifdef NEMO_STAMPS
 __device__ unsigned long long g_stamps[16];
-#define STAMP_DECL unsigned long long st_prev = (threadIdx.x == 0) ? __builtin_readcyclecounter() : 0ull
+#define STAMP_DECL unsigned long long st_prev = (threadIdx.x == 0) ? __builtin_amdgcn_s_memrealtime() : 0ull
 #define STAMP(i)                                                         \
   do {                                                                   \
     if (threadIdx.x == 0) {                                              \
-      const unsigned long long now_ = __builtin_readcyclecounter();      \
+      const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();      \
       atomicAdd(&g_stamps[i], now_ - st_prev);                           \
       st_prev = now_;                                                    \
     }                                                                    \
@@ -353,14 +359,20 @@ __device__ unsigned long long g_stamps[16];
 #endif
 
 // ---------------------------------------------------------------- LDS layout
+constexpr int FACE_BYTES = 8 + 16;  // per face: vertex ids (us4) + FaceRec (uint4)
+// FaceRec, written by the rasteriser for the list builder, per face and band:
+//   x = a_lo | a_hi << 16, y = b_lo | b_hi << 16 | masked << 31, (z, w) = 64-bit mask.
+// masked: the face's candidate box is at most 8 x 8 pixel centres; (a_lo.., b_lo..) is that box and bit
+//   8 * (b - b_lo) + (a - a_lo) of the mask says that the face produced a fragment there.
+// otherwise: the box is the bounding box of the face's fragments and the mask is unused.
 struct Lds {
   u64 *zb;               // [cap] packed z-buffer
   f4 *sv;                // [vmax] screen verts (u, t, z_view, -)
   us4 *fc;               // [fmax] face vertex ids (i0, i1, i2, -) as 16-bit
-  us4 *finfo;            // [fmax] per face, per band: box (a_lo, a_hi, b_lo, b_hi) of its fragments
+  u4v *finfo;            // [fmax] per face, per band: FaceRec (candidate / fragment box + 8x8 fragment mask)
   __attribute__((address_space(1))) f4 *gsv;     // BIG: the same three tables in global scratch
   __attribute__((address_space(1))) us4 *gfc;
-  __attribute__((address_space(1))) us4 *gfinfo;
+  __attribute__((address_space(1))) u4v *gfinfo;
   float *ndc;            // [S] pixel-centre NDC coordinate of flipped index a: PixToNdc(a, S)
   uint32_t *list;        // [cap] covered pixels, face-major: (face id << 16) | window pixel index
   float *red;            // [NW][RED_N]
@@ -408,7 +420,7 @@ __host__ __device__ inline size_t zb_region_bytes(int cap) {
   return ((a > b ? a : b) + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t lds_bytes(int cap, int vmax, int fmax, int wmax, int S) {
-  size_t b = zb_region_bytes(cap) + (size_t)cap * 4 + (size_t)vmax * 16 + (size_t)fmax * 16;
+  size_t b = zb_region_bytes(cap) + (size_t)cap * 4 + (size_t)vmax * 16 + (size_t)fmax * FACE_BYTES;
   b += (NW * RED_N + UST_N + ((S + 11) & ~3)) * 4 + 64;
   (void)wmax;
   return (b + 15) & ~(size_t)15;
@@ -420,7 +432,7 @@ __device__ __forceinline__ Lds lds_carve(unsigned char *base, const KParams &P) 
   L.sv = (f4 *)(base + (size_t)P.zb_bytes);
   const int vl = P.big ? 0 : P.vmax, fl = P.big ? 0 : P.fmax;  // table entries kept in LDS
   L.fc = (us4 *)(L.sv + vl);
-  L.finfo = L.fc + fl;
+  L.finfo = (u4v *)(L.fc + fl);
   L.list = (uint32_t *)(L.finfo + fl);
   L.red = (float *)(L.list + P.cap);
   L.ust = L.red + NW * RED_N;
@@ -428,7 +440,7 @@ __device__ __forceinline__ Lds lds_carve(unsigned char *base, const KParams &P) 
   unsigned char *g = (unsigned char *)(P.big_scratch + (unsigned long long)blockIdx.x * P.big_stride);
   L.gsv = (__attribute__((address_space(1))) f4 *)g;
   L.gfc = (__attribute__((address_space(1))) us4 *)(g + (size_t)P.vmax * 16);
-  L.gfinfo = L.gfc + P.fmax;
+  L.gfinfo = (__attribute__((address_space(1))) u4v *)(L.gfc + P.fmax);
   return L;
 }
 // Table accessors: LDS for ordinary meshes, the global scratch slice for BIG ones.
@@ -436,8 +448,13 @@ template <bool BIG> __device__ __forceinline__ f4 sv_at(const Lds &L, int i) { i
 template <bool BIG> __device__ __forceinline__ void sv_put(const Lds &L, int i, f4 v) { if constexpr (BIG) L.gsv[i] = v; else L.sv[i] = v; }
 template <bool BIG> __device__ __forceinline__ us4 fc_at(const Lds &L, int i) { if constexpr (BIG) return L.gfc[i]; else return L.fc[i]; }
 template <bool BIG> __device__ __forceinline__ void fc_put(const Lds &L, int i, us4 v) { if constexpr (BIG) L.gfc[i] = v; else L.fc[i] = v; }
-template <bool BIG> __device__ __forceinline__ us4 finfo_at(const Lds &L, int i) { if constexpr (BIG) return L.gfinfo[i]; else return L.finfo[i]; }
-template <bool BIG> __device__ __forceinline__ void finfo_put(const Lds &L, int i, us4 v) { if constexpr (BIG) L.gfinfo[i] = v; else L.finfo[i] = v; }
+template <bool BIG> __device__ __forceinline__ u4v finfo_at(const Lds &L, int i) { if constexpr (BIG) return L.gfinfo[i]; else return L.finfo[i]; }
+template <bool BIG> __device__ __forceinline__ void finfo_put(const Lds &L, int i, u4v v) { if constexpr (BIG) L.gfinfo[i] = v; else L.finfo[i] = v; }
+// The winners' mask of a face replaces its fragment mask (second half of the record).
+template <bool BIG> __device__ __forceinline__ void finfo_put_mask(const Lds &L, int i, u64 m) {
+  const u2v v = u2v{(uint32_t)m, (uint32_t)(m >> 32)};
+  if constexpr (BIG) *((__attribute__((address_space(1))) u2v *)(L.gfinfo + i) + 1) = v; else *((u2v *)(L.finfo + i) + 1) = v;
+}
 
 constexpr int MAX_GRIDS = 64;
 constexpr int GRID_POSES_PER_WG = 4;
@@ -874,15 +891,17 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       for (int i = tid; i < npx; i += NT) L.zb[i] = ~0ull;
       __syncthreads();
       STAMP(1);
-      // ---- 2b. face-parallel rasterisation (one thread per face)
+      // ---- 2b. face-parallel rasterisation (one thread per face).  The candidate pixel centres of a face
+      // (its exact bounding-box ranges) are walked as ONE flat loop, so a wave runs max-over-lanes of the
+      // candidate COUNT, not of rows x columns; the sign pre-test is branch-free; the three quotients
+      // e_k / area use the hoisted exact division (fastdiv.h), the IEEE expansion only for operands outside
+      // its safe range.  Every accepted fragment sees the same operations, in the same order, as the oracle.
       for (int f = tid; f < F; f += NT) {
         const us4 fv_ = fc_at<BIG>(L, f);
         const int i0 = fv_.x, i1 = fv_.y, i2 = fv_.z;
         float v[9];
         load_face_verts<BIG>(L, i0, i1, i2, v);
-        // box of the pixels where this face produced a fragment (empty: lo > hi); the list walks
-        // below look only there
-        int ha_lo = 1, ha_hi = 0, hb_lo = 1, hb_hi = 0;
+        u4v rec = u4v{1u, 1u | (1u << 31), 0u, 0u};  // empty box, empty mask
         if (!face_degenerate(v, P.keps)) {
           const float xmin = fminf(fminf(v[0], v[3]), v[6]), xmax = fmaxf(fmaxf(v[0], v[3]), v[6]);
           const float ymin = fminf(fminf(v[1], v[4]), v[7]), ymax = fmaxf(fmaxf(v[1], v[4]), v[7]);
@@ -892,23 +911,82 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
           exact_range(xmin, xmax, a_lo, a_hi, fa_lo, fa_hi);
           exact_range(ymin, ymax, bb, bb + nr - 1, fb_lo, fb_hi);
           if (fa_lo <= fa_hi && fb_lo <= fb_hi) {
-            const float area = face_area_eps(v, P.keps);
-            ha_lo = hb_lo = 0x7fff; ha_hi = hb_hi = -1;
-            for (int b = fb_lo; b <= fb_hi; ++b) {
-              const float py = L.ndc[b];
-              for (int a = fa_lo; a <= fa_hi; ++a) {
-                Frag fr;
-                if (!frag_eval<PERSP>(L.ndc[a], py, v, area, fr)) continue;
-                const u64 key = ((u64)__float_as_uint(fr.pz) << 32) | (u64)(uint32_t)f;
-                atomicMin(&L.zb[(b - bb) * bw + (a - a_lo)], key);
-                ha_lo = min(ha_lo, a); ha_hi = max(ha_hi, a);
-                hb_lo = min(hb_lo, b); hb_hi = max(hb_hi, b);
+            const float area0 = face_area_eps(v, P.keps);
+            const int na = fa_hi - fa_lo + 1, nb = fb_hi - fb_lo + 1, ncand = na * nb;
+            const bool use_mask = na <= 8 && nb <= 8;
+            // Orientation: with a negative area every edge value and the area are negated (exact, and
+            // e / area == (-e) / (-area) bit for bit), so the pre-test below is "all edge values > 0"
+            // for either winding.  odd: zero / NaN area, no pre-test possible.
+            const bool odd = !(area0 > 0.0f || area0 < 0.0f);
+            const float sg = area0 < 0.0f ? -1.0f : 1.0f;
+            const float area = area0 * sg;
+            // edge(p; a, b) = (p.x - a.x)(b.y - a.y) - (p.y - a.y)(b.x - a.x): the per-face and per-row factors
+            const float dy0 = (v[7] - v[4]) * sg, dx0 = (v[6] - v[3]) * sg;
+            const float dy1 = (v[1] - v[7]) * sg, dx1 = (v[0] - v[6]) * sg;
+            const float dy2 = (v[4] - v[1]) * sg, dx2 = (v[3] - v[0]) * sg;
+            const FastDiv fd(area);
+            // |edge value| <= 4 M (1 + M) for pixel centres in [-1, 1] and |vertex x, y| <= M: with M <= 2^18
+            // only the lower end of FastDiv's safe range is left to check per candidate.
+            const float mabs = fmaxf(fmaxf(fabsf(xmin), fabsf(xmax)), fmaxf(fabsf(ymin), fabsf(ymax)));
+            const float thr = (fd.d_safe && mabs <= 0x1p18f && !odd) ? 0x1p-40f : INFINITY;
+            int a = fa_lo, b = fb_lo, bit = 0;
+            float py = L.ndc[b];
+            float r0 = (py - v[4]) * dx0, r1 = (py - v[7]) * dx1, r2 = (py - v[1]) * dx2;
+            int ha_lo = 0x7fff, ha_hi = -1, hb_lo = 0x7fff, hb_hi = -1;
+            u64 fmask = 0;
+            u64 *zrow = L.zb + ((b - bb) * bw - a_lo);
+            for (int c = 0; c < ((NEMO_RABL & 1) ? 0 : ncand); ++c) {
+              const float px = L.ndc[a];
+              const float e0 = (px - v[3]) * dy0 - r0;
+              const float e1 = (px - v[6]) * dy1 - r1;
+              const float e2 = (px - v[0]) * dy2 - r2;
+              // the quotients can only all be > 0 if every (oriented) edge value is; min3 skips NaNs, which
+              // the explicit comparisons on the quotients below reject like the reference does
+              const float m = PERSP ? fminf(fminf(fabsf(e0), fabsf(e1)), fabsf(e2)) : fminf(fminf(e0, e1), e2);
+              if (PERSP || odd || m > 0.0f) {
+                float w0, w1, w2;
+                if (m >= thr) {
+                  w0 = fd.div(e0); w1 = fd.div(e1); w2 = fd.div(e2);
+                } else {
+                  w0 = e0 / area; w1 = e1 / area; w2 = e2 / area;
+                }
+                float b0 = w0, b1 = w1, b2 = w2;
+                if (PERSP) {
+                  const float t0 = (w0 * v[5]) * v[8];
+                  const float t1 = (v[2] * w1) * v[8];
+                  const float t2 = (v[2] * v[5]) * w2;
+                  const float den = (t0 + t1) + t2;
+                  b0 = t0 / den; b1 = t1 / den; b2 = t2 / den;
+                }
+                const float pz = (b0 * v[2] + b1 * v[5]) + b2 * v[8];
+                if (!(pz < 0.0f) && b0 > 0.0f && b1 > 0.0f && b2 > 0.0f) {
+                  const u64 key = ((u64)__float_as_uint(pz + 0.0f) << 32) | (u64)(uint32_t)f;  // -0 -> +0: key order = float order
+                  atomicMin(&zrow[a], key);
+                  fmask |= 1ull << (bit & 63);
+                  if (__builtin_expect(!use_mask, 0)) {
+                    ha_lo = min(ha_lo, a); ha_hi = max(ha_hi, a);
+                    hb_lo = min(hb_lo, b); hb_hi = max(hb_hi, b);
+                  }
+                }
+              }
+              ++a; ++bit;
+              if (a > fa_hi) {  // next row of the candidate box (the NDC table has two spare entries past S - 1)
+                a = fa_lo; ++b; bit += 8 - na;
+                zrow += bw;
+                py = L.ndc[b];
+                r0 = (py - v[4]) * dx0; r1 = (py - v[7]) * dx1; r2 = (py - v[1]) * dx2;
               }
             }
-            if (ha_hi < 0) { ha_lo = hb_lo = 1; ha_hi = hb_hi = 0; }
+            if (use_mask) {
+              rec = u4v{(uint32_t)fa_lo | ((uint32_t)fa_hi << 16), (uint32_t)fb_lo | ((uint32_t)fb_hi << 16) | (1u << 31),
+                          (uint32_t)fmask, (uint32_t)(fmask >> 32)};
+            } else {
+              if (ha_hi < 0) { ha_lo = hb_lo = 1; ha_hi = hb_hi = 0; }
+              rec = u4v{(uint32_t)ha_lo | ((uint32_t)ha_hi << 16), (uint32_t)hb_lo | ((uint32_t)hb_hi << 16), 0u, 0u};
+            }
           }
         }
-        finfo_put<BIG>(L, f, us4{(unsigned short)ha_lo, (unsigned short)ha_hi, (unsigned short)hb_lo, (unsigned short)hb_hi});
+        finfo_put<BIG>(L, f, rec);
       }
       __syncthreads();
       STAMP(2);
@@ -917,20 +995,34 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       // block-wide exclusive scan of the per-thread counts gives every thread its slot
       // range; the order (hence every later float sum) is deterministic.  An entry
       // packs (face id << 16) | window pixel index, all the score phases need.
+      // Masked faces: the count pass visits only the pixels where the face produced a fragment and
+      // leaves the mask of those it won in the record; the fill pass visits only the winners.
       const uint32_t *zlo = (const uint32_t *)L.zb;  // low dword of a key = face id
       const int fpl = (F + NT - 1) / NT;
       const int fbeg = min(F, tid * fpl), fend = min(F, fbeg + fpl);
-      auto walk = [&](auto &&visit) {
-        for (int f = fbeg; f < fend; ++f) {
-          const us4 fi = finfo_at<BIG>(L, f);
-          const int fa_lo = fi.x, fa_hi = fi.y, fb_lo = fi.z, fb_hi = fi.w;
-          for (int b = fb_lo; b <= fb_hi; ++b)
-            for (int a = fa_lo; a <= fa_hi; ++a)
-              if (zlo[2 * ((b - bb) * bw + (a - a_lo))] == (uint32_t)f) visit(f, a, b);
-        }
+      auto zface = [&](int a, int b) { return zlo[2 * ((b - bb) * bw + (a - a_lo))]; };
+      auto pack = [&](int f, int a, int b) {
+        return ((uint32_t)f << 16) | (uint32_t)((S - 1 - b - P.r0) * P.w + (S - 1 - a - P.c0));
       };
       int cnt = 0;
-      walk([&](int, int, int) { ++cnt; });
+      for (int f = fbeg; f < fend; ++f) {
+        const u4v fi = finfo_at<BIG>(L, f);
+        const int fa_lo = fi.x & 0xffffu, fa_hi = fi.x >> 16, fb_lo = fi.y & 0xffffu, fb_hi = (fi.y >> 16) & 0x7fffu;
+        if (fi.y >> 31) {
+          u64 m = (u64)fi.z | ((u64)fi.w << 32), won = 0;
+          if (m == 0) continue;
+          while (m) {
+            const int c = __builtin_ctzll(m);
+            m &= m - 1;
+            if (zface(fa_lo + (c & 7), fb_lo + (c >> 3)) == (uint32_t)f) won |= 1ull << c;
+          }
+          cnt += __builtin_popcountll(won);
+          finfo_put_mask<BIG>(L, f, won);
+        } else {
+          for (int b = fb_lo; b <= fb_hi; ++b)
+            for (int a = fa_lo; a <= fa_hi; ++a) cnt += (int)(zface(a, b) == (uint32_t)f);
+        }
+      }
       int incl = cnt;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
@@ -949,9 +1041,22 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       }
       ntot = __builtin_amdgcn_readfirstlane(ntot);
       if (cnt > 0)
-        walk([&](int f, int a, int b) {
-          L.list[slot++] = ((uint32_t)f << 16) | (uint32_t)((S - 1 - b - P.r0) * P.w + (S - 1 - a - P.c0));
-        });
+        for (int f = fbeg; f < fend; ++f) {
+          const u4v fi = finfo_at<BIG>(L, f);
+          const int fa_lo = fi.x & 0xffffu, fa_hi = fi.x >> 16, fb_lo = fi.y & 0xffffu, fb_hi = (fi.y >> 16) & 0x7fffu;
+          if (fi.y >> 31) {
+            u64 m = (u64)fi.z | ((u64)fi.w << 32);  // winners, row-major (bit order = b, then a)
+            while (m) {
+              const int c = __builtin_ctzll(m);
+              m &= m - 1;
+              L.list[slot++] = pack(f, fa_lo + (c & 7), fb_lo + (c >> 3));
+            }
+          } else {
+            for (int b = fb_lo; b <= fb_hi; ++b)
+              for (int a = fa_lo; a <= fa_hi; ++a)
+                if (zface(a, b) == (uint32_t)f) L.list[slot++] = pack(f, a, b);
+          }
+        }
       ncov += (tid == 0) ? ntot : 0;
       __syncthreads();
       STAMP(3);
@@ -1487,6 +1592,52 @@ __global__ void grid_argmin_kernel(int N, int G, const float *losses, const int3
   }
 }
 
+// Launch order of the solve (scheduling only; results do not depend on it).  A solve is one workgroup per job
+// for all 300 steps, a CU holds one workgroup, and a job's cost grows with the pixels its object covers
+// (1.2k .. 6k at the bench workload), so with only a few jobs per CU the launch ends when the unluckiest CU
+// does.  Jobs are therefore started longest first: solve_cost_kernel counts the covered pixels at the
+// initial pose (one rasterisation per job, 1/steps of the solve's work) and solve_order_kernel sorts the job
+// ids by that count, descending (counting sort, 64-pixel buckets); workgroup b of the solve runs job order[b].
+template <bool PERSP, bool BIG>
+__global__ __launch_bounds__(NT, 4) void solve_cost_kernel(KParams P, const MeshDesc *meshes, const int32_t *mesh_idx,
+                                                           const float *C0, const float *theta0, const float *trans0,
+                                                           int32_t *cost) {
+  const int n = blockIdx.x;
+  const MeshDesc M = meshes[mesh_idx ? mesh_idx[n] : 0];
+  const Lds L = lds_carve(smem, P);
+  load_world_verts<BIG>(P, L, M);
+  if (threadIdx.x == 0) {
+    const float Cp[3] = {C0[3 * n], C0[3 * n + 1], C0[3 * n + 2]};
+    const float ex[3] = {trans0 ? trans0[2 * n] : 0.f, trans0 ? trans0[2 * n + 1] : 0.f, 0.f};
+    Cam cam;
+    ust_set_camera(L, Cp, theta0[n], cam, trans0 ? ex : nullptr);
+  }
+  __syncthreads();
+  EmitOut e{};
+  eval_pose<128, PERSP, false, false, false, false, BIG>(P, L, M, nullptr, nullptr, e);
+  if (threadIdx.x == 0) cost[n] = (int)(block_total(L, T_NCOV) + 0.5f);
+}
+
+constexpr int SO_BUCKETS = 1024;
+__global__ __launch_bounds__(1024) void solve_order_kernel(int N, const int32_t *cost, int32_t *order) {
+  __shared__ int cnt[SO_BUCKETS];
+  auto bucket = [](int c) { return SO_BUCKETS - 1 - min(max(c, 0) >> 6, SO_BUCKETS - 1); };  // bucket 0 = most pixels
+  for (int i = threadIdx.x; i < SO_BUCKETS; i += blockDim.x) cnt[i] = 0;
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += blockDim.x) atomicAdd(&cnt[bucket(cost[n])], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int i = 0; i < SO_BUCKETS; ++i) {
+      const int c = cnt[i];
+      cnt[i] = run;  // becomes the placement cursor
+      run += c;
+    }
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += blockDim.x) order[atomicAdd(&cnt[bucket(cost[n])], 1)] = n;
+}
+
 // The fused solve: code/MeshPoseSolveAll.py:227-250 in one launch.  Thread 0
 // runs the serial part of every step (camera, camera backward, Adam) and hands
 // R, T to the workgroup through LDS; (C, theta) and the Adam moments live in LDS.
@@ -1496,8 +1647,9 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
                                                       const float *C0, const float *theta0, const float *trans0,
                                                       int ndof, const float *adam_tab, int steps, float beta1,
                                                       float beta2, float eps, float *pose, float *loss_out,
-                                                      float *trace, u64 *counter, int stagger) {
-  const int n = blockIdx.x;
+                                                      float *trace, u64 *counter, int stagger,
+                                                      const int32_t *order) {
+  const int n = order ? order[blockIdx.x] : (int)blockIdx.x;  // longest job first (solve_order_kernel)
   const MeshDesc M = meshes[mesh_idx ? mesh_idx[n] : 0];
   const int img = img_idx ? img_idx[n] : n;
   const size_t hw = (size_t)P.h * P.w;
@@ -1535,7 +1687,7 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
   for (int t = 0; t < steps; ++t) {
     eval_pose<D, PERSP, true, true, false, false, BIG>(P, L, M, f, c, none);
 #ifdef NEMO_STAMPS
-    const unsigned long long st_lead = (threadIdx.x == 0) ? __builtin_readcyclecounter() : 0ull;
+    const unsigned long long st_lead = (threadIdx.x == 0) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 #endif
     if (lead) {
       float p[6] = {L.ust[U_P], L.ust[U_P + 1], L.ust[U_P + 2], L.ust[U_P + 3], L.ust[U_P6], L.ust[U_P6 + 1]};
@@ -1578,7 +1730,7 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
     __syncthreads();
 #ifdef NEMO_STAMPS
     if (threadIdx.x == 0) {
-      const unsigned long long now_ = __builtin_readcyclecounter();
+      const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();
       atomicAdd(&g_stamps[7], now_ - st_lead);
     }
 #endif
@@ -1705,6 +1857,8 @@ struct nemo_ctx {
   size_t gs_jobs_cap, gs_partial_cap;
   unsigned char *d_big;  // BIG-mesh table scratch
   size_t big_cap;
+  int32_t *d_so;         // solve launch order workspace: cost[so_cap], order[so_cap]
+  size_t so_cap;
   char err[512];
 };
 
@@ -1744,7 +1898,7 @@ static int plan_lds(nemo_ctx *ctx) {
     if (avail - fixed < cap * 4 + 64 * (cap / CH)) cap = (avail - fixed) / 5;
     return cap;
   };
-  long cap = cap_for((long)LDS_BUDGET - (long)vmax * 16 - (long)fmax * 16 - misc);
+  long cap = cap_for((long)LDS_BUDGET - (long)vmax * 16 - (long)fmax * FACE_BYTES - misc);
   int big = 0;
   if (cap < c.win_w || cap < (hw < 2048 ? hw : 2048)) {
     // the mesh tables would leave (almost) no z-buffer: keep them in global scratch instead (BIG kernels)
@@ -1757,7 +1911,7 @@ static int plan_lds(nemo_ctx *ctx) {
   ctx->P.vmax = vmax;
   ctx->P.fmax = fmax;
   ctx->P.big = big;
-  ctx->P.big_stride = (unsigned)(((size_t)vmax * 16 + (size_t)fmax * 16 + 255) & ~(size_t)255);
+  ctx->P.big_stride = (unsigned)(((size_t)vmax * 16 + (size_t)fmax * FACE_BYTES + 255) & ~(size_t)255);
   ctx->P.zb_bytes = (int)zb_region_bytes((int)cap);
   ctx->P.w_magic = (unsigned)(0x100000000ULL / (unsigned long long)c.win_w) + 1u;
   ctx->lds = lds_bytes((int)cap, big ? 0 : vmax, big ? 0 : fmax, c.win_w, c.raster_size);
@@ -1861,6 +2015,7 @@ int nemo_ctx_create(const nemo_config *cfg, nemo_ctx **out) {
 #define SET_LDS_B(k, ...) SET_LDS((k<__VA_ARGS__, false>)); SET_LDS((k<__VA_ARGS__, true>))
   SET_LDS_B(raster_kernel, false); SET_LDS_B(raster_kernel, true);
   SET_LDS_B(prerender_kernel, false); SET_LDS_B(prerender_kernel, true);
+  SET_LDS_B(solve_cost_kernel, false); SET_LDS_B(solve_cost_kernel, true);
   SET_LDS_B(score_kernel, 128, false); SET_LDS_B(score_kernel, 128, true);
   SET_LDS_B(score_kernel, 256, false); SET_LDS_B(score_kernel, 256, true);
   SET_LDS_B(grid_kernel, 128, false); SET_LDS_B(grid_kernel, 128, true);
@@ -1882,7 +2037,7 @@ int nemo_ctx_destroy(nemo_ctx *ctx) {
   hipFree(ctx->d_adam);
   hipFree(ctx->d_pre_slot); hipFree(ctx->d_pre_cnt); hipFree(ctx->d_pre_pairs); hipFree(ctx->d_pre_list);
   hipFree(ctx->d_pre_maps); hipFree(ctx->d_gs_order); hipFree(ctx->d_gs_start); hipFree(ctx->d_gs_jobslot);
-  hipFree(ctx->d_gs_partial); hipFree(ctx->d_big);
+  hipFree(ctx->d_gs_partial); hipFree(ctx->d_big); hipFree(ctx->d_so);
   delete ctx;
   return NEMO_OK;
 }
@@ -2134,39 +2289,58 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
   return NEMO_OK;
 }
 
-int nemo_solve(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t *d_mesh_idx, const float *d_feat,
-               const float *d_clu, const float *d_C0, const float *d_theta0, float *d_pose, float *d_loss,
-               float *d_trace, void *stream) {
-  int rc = check_ready(ctx, "nemo_solve", N);
+// Shared by nemo_solve / nemo_solve6: launch order (longest job first), then the fused solve.
+static int launch_solve(nemo_ctx *ctx, const char *who, int32_t N, const int32_t *d_img_idx, const int32_t *d_mesh_idx,
+                        const float *d_feat, const float *d_clu, const float *d_C0, const float *d_theta0,
+                        const float *d_trans0, int ndof, float *d_pose, float *d_loss, float *d_trace, void *stream) {
+  int rc = check_ready(ctx, who, N);
   if (rc) return rc > 0 ? NEMO_OK : rc;
-  if (ctx->adam_steps <= 0) return fail(ctx, NEMO_ERR_STATE, "nemo_solve: call nemo_set_schedule first");
-  if (!d_feat || !d_C0 || !d_theta0 || !d_pose) return fail(ctx, NEMO_ERR_ARG, "nemo_solve: null buffer");
-  if (ctx->cfg.clutter && !d_clu) return fail(ctx, NEMO_ERR_ARG, "nemo_solve: clutter loss needs d_clu");
+  if (ctx->adam_steps <= 0) return fail(ctx, NEMO_ERR_STATE, "%s: call nemo_set_schedule first", who);
+  if (!d_feat || !d_C0 || !d_theta0 || !d_pose) return fail(ctx, NEMO_ERR_ARG, "%s: null buffer", who);
+  if (ctx->cfg.clutter && !d_clu) return fail(ctx, NEMO_ERR_ARG, "%s: clutter loss needs d_clu", who);
+  if (ctx->P.big && (unsigned)N > BIG_MAX_BLOCKS)
+    return fail(ctx, NEMO_ERR_UNSUPPORTED, "%s: %d jobs in one call with a large mesh (limit %u)", who, N, BIG_MAX_BLOCKS);
   // start stagger in units of (slot x 8128-cycle sleeps): spread ~128 slots over about one step
   const char *stg = getenv("NEMO_SOLVE_STAGGER");
   const int stagger = stg ? atoi(stg) : 1;
-  DISPATCH_DP(solve_kernel, dim3(N), ctx->P, ctx->d_meshes, d_img_idx, d_mesh_idx, d_feat, d_clu, d_C0, d_theta0,
-              (const float *)nullptr, 4, ctx->d_adam, ctx->adam_steps, ctx->beta1, ctx->beta2, ctx->eps, d_pose, d_loss,
-              d_trace, ctx->d_counter, stagger);
+  // launch order: only worth it when some CU gets more than one job (NEMO_SOLVE_ORDER=0 turns it off)
+  const char *ord = getenv("NEMO_SOLVE_ORDER");
+  const int32_t *d_order = nullptr;
+  if (N > 64 && !(ord && atoi(ord) == 0)) {
+    if ((size_t)N > ctx->so_cap) {
+      hipFree(ctx->d_so);
+      ctx->d_so = nullptr;
+      ctx->so_cap = 0;
+      HIP_TRY(ctx, hipMalloc((void **)&ctx->d_so, sizeof(int32_t) * 2 * (size_t)N));
+      ctx->so_cap = (size_t)N;
+    }
+    int32_t *d_cost = ctx->d_so, *d_ord = ctx->d_so + ctx->so_cap;
+    if ((rc = ensure_big_scratch(ctx, (size_t)N)) != NEMO_OK) return rc;
+    LAUNCH_PB(solve_cost_kernel, dim3(N), (hipStream_t)stream, ctx->P, ctx->d_meshes, d_mesh_idx, d_C0, d_theta0,
+              ndof == 6 ? d_trans0 : (const float *)nullptr, d_cost);
+    hipLaunchKernelGGL(solve_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (int)N, (const int32_t *)d_cost, d_ord);
+    HIP_TRY(ctx, hipGetLastError());
+    d_order = d_ord;
+  }
+  DISPATCH_DP(solve_kernel, dim3(N), ctx->P, ctx->d_meshes, d_img_idx, d_mesh_idx, d_feat, d_clu, d_C0, d_theta0, d_trans0,
+              ndof, ctx->d_adam, ctx->adam_steps, ctx->beta1, ctx->beta2, ctx->eps, d_pose, d_loss, d_trace, ctx->d_counter,
+              stagger, d_order);
   HIP_TRY(ctx, hipGetLastError());
   return NEMO_OK;
+}
+
+int nemo_solve(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t *d_mesh_idx, const float *d_feat,
+               const float *d_clu, const float *d_C0, const float *d_theta0, float *d_pose, float *d_loss,
+               float *d_trace, void *stream) {
+  return launch_solve(ctx, "nemo_solve", N, d_img_idx, d_mesh_idx, d_feat, d_clu, d_C0, d_theta0, nullptr, 4, d_pose,
+                      d_loss, d_trace, stream);
 }
 
 int nemo_solve6(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t *d_mesh_idx, const float *d_feat,
                 const float *d_clu, const float *d_C0, const float *d_theta0, const float *d_trans0, float *d_pose6,
                 float *d_loss, float *d_trace, void *stream) {
-  int rc = check_ready(ctx, "nemo_solve6", N);
-  if (rc) return rc > 0 ? NEMO_OK : rc;
-  if (ctx->adam_steps <= 0) return fail(ctx, NEMO_ERR_STATE, "nemo_solve6: call nemo_set_schedule first");
-  if (!d_feat || !d_C0 || !d_theta0 || !d_pose6) return fail(ctx, NEMO_ERR_ARG, "nemo_solve6: null buffer");
-  if (ctx->cfg.clutter && !d_clu) return fail(ctx, NEMO_ERR_ARG, "nemo_solve6: clutter loss needs d_clu");
-  const char *stg = getenv("NEMO_SOLVE_STAGGER");
-  const int stagger = stg ? atoi(stg) : 1;
-  DISPATCH_DP(solve_kernel, dim3(N), ctx->P, ctx->d_meshes, d_img_idx, d_mesh_idx, d_feat, d_clu, d_C0, d_theta0,
-              d_trans0, 6, ctx->d_adam, ctx->adam_steps, ctx->beta1, ctx->beta2, ctx->eps, d_pose6, d_loss, d_trace,
-              ctx->d_counter, stagger);
-  HIP_TRY(ctx, hipGetLastError());
-  return NEMO_OK;
+  return launch_solve(ctx, "nemo_solve6", N, d_img_idx, d_mesh_idx, d_feat, d_clu, d_C0, d_theta0, d_trans0, 6, d_pose6,
+                      d_loss, d_trace, stream);
 }
 
 int nemo_interpolate_backward(nemo_ctx *ctx, const int32_t *d_mesh_idx, const float *d_R, const float *d_T,

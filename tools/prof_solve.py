@@ -17,6 +17,7 @@ ap.add_argument('--images', type=int, default=512)
 ap.add_argument('--steps', type=int, default=60)
 ap.add_argument('--reps', type=int, default=2)
 ap.add_argument('--grid', action='store_true', help='also time the grid search')
+ap.add_argument('--sort', action='store_true', help='order the jobs by descending coverage at the initial pose (longest first)')
 ap.add_argument('--lr0', action='store_true', help='zero learning rate: every step re-evaluates the initial pose (fixed work for ablations)')
 args = ap.parse_args()
 wl = twelve_class_workload(args.images, seed=1000, cfg=SolverConfig(total_epochs=args.steps, **({'lr': 0.0} if args.lr0 else {})))
@@ -24,13 +25,21 @@ s, eng = wl.solver, wl.solver.engine
 clu = eng.clutter_score(wl.feats, wl.clutter)
 C0, th0, _, _ = eng.grid_search(wl.feats, clu, s.grid_C, s.grid_theta, mesh_idx=wl.mesh_idx, grid_idx=wl.mesh_idx)
 torch.cuda.synchronize()
+img_idx, mesh_idx = None, wl.mesh_idx
+if args.sort:
+    _, _, ncov = eng.score_fwd_bwd(wl.feats, clu, C0, th0, mesh_idx=wl.mesh_idx, want_grad=False)
+    perm = torch.argsort(ncov, descending=True)
+    print('coverage at the initial pose: min %d median %d max %d' % (ncov.min().item(), ncov.median().item(), ncov.max().item()))
+    img_idx, mesh_idx = perm.to(torch.int32), wl.mesh_idx[perm].contiguous()
+    C0, th0 = C0[perm].contiguous(), th0[perm].contiguous()
+    torch.cuda.synchronize()
 for r in range(args.reps):
     if os.environ.get('NEMO_HIP_LIB') and hasattr(eng.lib, 'nemo_debug_stamps'):
         import ctypes
         eng.lib.nemo_debug_stamps((ctypes.c_ulonglong * 16)())
     eng.counter_reset()
     t0 = time.perf_counter()
-    eng.solve(wl.feats, clu, C0, th0, mesh_idx=wl.mesh_idx)
+    eng.solve(wl.feats, clu, C0, th0, img_idx=img_idx, mesh_idx=mesh_idx)
     cov = eng.counter_read()
     dt = time.perf_counter() - t0
     print(f'solve: {args.images} images x {args.steps} steps: {dt*1e3:.2f} ms, {dt*1e6/args.steps:.1f} us/step, '
@@ -43,6 +52,9 @@ if os.environ.get('NEMO_HIP_LIB'):
         tot = sum(st[:8]) or 1
         print('score split: phaseA %.1f%% phaseB %.1f%% of total' % (100*st[8]/(tot+st[8]+st[9]-st[4]), 100*st[9]/(tot+st[8]+st[9]-st[4])))
         print('phase shares (wave-0 cycles, last solve): ' + ', '.join(f'{n} {100*st[i]/tot:.1f}%' for i, n in enumerate(names)))
+        per = 1.0 / (args.images * args.steps)
+        print('wave-0 us per job-step (100 MHz wall clock): ' + ', '.join(f'{n} {st[i]*per/100:.2f}' for i, n in enumerate(names)) +
+              f', phaseA {st[8]*per/100:.2f}, phaseB {st[9]*per/100:.2f}')
 if args.grid:
     s.prerender()
     for r in range(args.reps):
