@@ -39,7 +39,7 @@ constexpr int NT = NEMO_NT;    // threads per workgroup of the pose kernels
 constexpr int NW = NT / 64;    // waves per workgroup
 constexpr int RED_N = 16;      // floats per wave in the reduction scratch
 #ifndef NEMO_CHUNK
-#define NEMO_CHUNK 128
+#define NEMO_CHUNK 64
 #endif
 constexpr int CH = NEMO_CHUNK;  // covered pixels per score chunk (multiple of 64)
 constexpr int UST_N = 96;      // floats of workgroup-uniform state kept in LDS
@@ -336,6 +336,9 @@ __device__ __forceinline__ float wave_max(float v) {
 // Diagnostic build only (-DNEMO_STAMPS): wave 0 / lane 0 of every workgroup adds the
 // cycles it spent per phase (barrier waits included) into g_stamps; the shipped
 // library contains none of this.
+#ifndef NEMO_SEG
+#define NEMO_SEG 1  // 1: static wave-contiguous score segments, one reduction per wave; 0: dynamic guided chunks
+#endif
 #ifndef NEMO_RABL
 #define NEMO_RABL 0  // rasteriser ablations (diagnostic builds): 1 = no candidate loop, 2 = candidates never accepted
 #endif
@@ -578,6 +581,9 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
   int ncov = 0, ebase = 0;
 
   // ---- consumer of one band's face-major list (L.list[0..ntot)): emit or score; ends behind a barrier
+#ifdef NEMO_STAMPS
+  unsigned long long st_score0 = 0;
+#endif
   auto consume = [&](const int ntot, const int ebase) {
     if (!SCORE) {
       // pre-render: keep the list itself; standalone rasterizer: emit pix_to_face / bary / zbuf
@@ -620,29 +626,59 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       constexpr int GPW = 64 / LPP;
       constexpr int NP = GRAD ? 13 : 1;  // partials per chunk: loss term, dL/dR (9), dL/dT (3)
       const int gl = lane & (LPP - 1), grp = lane / LPP;
+#ifdef NEMO_STAMPS
+      st_score0 = __builtin_amdgcn_s_memrealtime();
+#endif
       const ChunkPlan cp = plan_chunks(ntot);
       const int nchunks = cp.nchunks;
       float *part = (float *)L.zb;                                  // [nchunks][16]
       uint4 *rec = (uint4 *)(part + (size_t)max_chunks(P.cap) * 16) + wave * CH;               // [NW][CH]
       float *gbuf = (float *)((uint4 *)(part + (size_t)max_chunks(P.cap) * 16) + NW * CH) + wave * (CH * 3);  // [NW][CH*3]
       int *ctr = (int *)(L.ust + U_CTR);
+#ifdef NEMO_STATIC_CHUNKS
+      int static_next = wave;  // diagnostic build: round-robin static chunk assignment
+      auto grab = [&]() { const int v = static_next; static_next += NW; (void)ctr; return v; };
+#else
       auto grab = [&]() {
         int v = 0;
         if (lane == 0) v = atomicAdd(ctr, 1);
         return __builtin_amdgcn_readfirstlane(v);
       };
+#endif
       // rows are addressed as uniform base + 32-bit byte offset (feature window and bank are < 4 GiB)
       typedef const __attribute__((address_space(1))) char *gbytep;
       const gbytep fbytes = (gbytep)gfeat, bbytes = (gbytep)bank;
       const uint32_t gl16 = (uint32_t)gl * 16u;
-      auto first_off = [&](int c) {  // byte offset of the feature row of this lane group's first entry in chunk c
-        int cb_, cn_;
-        chunk_range(cp, ntot, c, cb_, cn_);
+      // byte offset of the feature row of this lane group's first entry in the chunk [cb_, cb_ + cn_)
+      auto first_off_at = [&](int cb_, int cn_) {
         const int per_ = (cn_ + GPW - 1) / GPW;
         return (L.list[cb_ + min(grp * per_, cn_ - 1)] & 0xffffu) * (uint32_t)(D * 4) + gl16;
       };
-      int ccur = grab(), cnxt = grab();
+      auto first_off = [&](int c) {
+        int cb_, cn_;
+        chunk_range(cp, ntot, c, cb_, cn_);
+        return first_off_at(cb_, cn_);
+      };
       f4 xa[KIT], xb[KIT];  // ping-pong: current / next feature-row fragments
+#if NEMO_SEG
+      // Static split: wave w owns the contiguous entries [ntot w / NW, ntot (w + 1) / NW) and walks them in
+      // chunks of CH; its 13 sums stay in registers across chunks and are reduced across lanes once.
+      const int seg_b = (ntot * wave) / NW, seg_e = (ntot * (wave + 1)) / NW;
+      float pl = 0.f;
+      float GR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      float GT[3] = {0.f, 0.f, 0.f};
+      int cb = seg_b;
+      (void)first_off; (void)grab; (void)nchunks;
+      if (cb < seg_e) {
+        const gf4p Fp = (gf4p)(fbytes + first_off_at(cb, min(CH, seg_e - cb)));
+#pragma unroll
+        for (int k = 0; k < KIT; ++k) xa[k] = __builtin_nontemporal_load(Fp + LPP * k);
+      }
+      while (cb < seg_e) {
+        const int cn = min(CH, seg_e - cb);
+        const int cb_next = cb + CH;
+#else
+      int ccur = grab(), cnxt = grab();
       if (ccur < nchunks) {
         const gf4p Fp = (gf4p)(fbytes + first_off(ccur));
 #pragma unroll
@@ -651,6 +687,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       while (ccur < nchunks) {
         int cb, cn;
         chunk_range(cp, ntot, ccur, cb, cn);
+#endif
         const int per = (cn + GPW - 1) / GPW;  // entries per lane group in this chunk
         // ---------------- records (one lane per entry): everything phase A needs to know about an entry
         // -- feature-row byte offset and the three bank rows -- is worked out once here, 64 entries per
@@ -674,7 +711,11 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
           // first feature row of this group in the wave's next chunk (or a harmless reload at the very end)
           const int e0 = grp * per;
           uint4 R0 = rec[min(e0, cn - 1)], R1 = rec[min(e0 + 1, cn - 1)];  // records run two entries ahead
+#if NEMO_SEG
+          const uint32_t off_next_chunk = cb_next < seg_e ? first_off_at(cb_next, min(CH, seg_e - cb_next)) : R0.x + gl16;
+#else
           const uint32_t off_next_chunk = cnxt < nchunks ? first_off(cnxt) : R0.x + gl16;
+#endif
           int i0 = -1, i1 = -1, i2 = -1;
           f4 y0[KIT], y1[KIT], y2[KIT];
 #pragma unroll
@@ -746,9 +787,11 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
         }
         STAMP(8);
         // ---------------- phase B: this lane's pixels -> its 13 contributions
+#if !NEMO_SEG
         float pl = 0.f;
         float GR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float GT[3] = {0.f, 0.f, 0.f};
+#endif
 #pragma unroll
         for (int u = 0; u < CH / 64; ++u)
         if (u * 64 + lane < cn) {
@@ -832,7 +875,14 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
             }
           }
         }
-        // chunk partials (fixed DPP tree), written by one lane
+#if NEMO_SEG
+        STAMP(9);
+        cb = cb_next;
+      }
+      const int pslot = wave;  // the wave's partials (fixed DPP tree), written by one lane
+#else
+        const int pslot = ccur;  // chunk partials (fixed DPP tree), written by one lane
+#endif
         {
           float pv[13];
           pv[0] = wave_sum_dpp(pl);
@@ -844,22 +894,33 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
           }
           if (lane == 0) {
 #pragma unroll
-            for (int i = 0; i < NP; ++i) part[ccur * 16 + i] = pv[i];
+            for (int i = 0; i < NP; ++i) part[pslot * 16 + i] = pv[i];
           }
         }
+#if !NEMO_SEG
         STAMP(9);
         ccur = cnxt;
         cnxt = grab();
       }
+#endif
     }
     STAMP(4);
+#ifdef NEMO_STAMPS
+    const unsigned long long st_arrive = __builtin_amdgcn_s_memrealtime();
+#endif
     __syncthreads();  // all chunks of the band are done
+#ifdef NEMO_STAMPS
+    if (SCORE && (threadIdx.x & 63) == 0) {  // every wave: its wait at the band barrier, and its busy time in the score loop
+      atomicAdd(&g_stamps[10], __builtin_amdgcn_s_memrealtime() - st_arrive);
+      atomicAdd(&g_stamps[11], st_arrive - st_score0);
+    }
+#endif
     if (SCORE) {
       // chunk partials -> running totals, in chunk order, one lane per total (wave 0 owns U_TOT)
       constexpr int NPB = GRAD ? 13 : 1;
       if (wave == 0 && lane < NPB) {
         const float *part = (const float *)L.zb;
-        const int nchunks = plan_chunks(ntot).nchunks;
+        const int nchunks = NEMO_SEG ? NW : plan_chunks(ntot).nchunks;
         float t = L.ust[U_TOT + lane];
         for (int c = 0; c < nchunks; ++c) t += part[c * 16 + lane];
         L.ust[U_TOT + lane] = t;
@@ -2302,7 +2363,7 @@ static int launch_solve(nemo_ctx *ctx, const char *who, int32_t N, const int32_t
     return fail(ctx, NEMO_ERR_UNSUPPORTED, "%s: %d jobs in one call with a large mesh (limit %u)", who, N, BIG_MAX_BLOCKS);
   // start stagger in units of (slot x 8128-cycle sleeps): spread ~128 slots over about one step
   const char *stg = getenv("NEMO_SOLVE_STAGGER");
-  const int stagger = stg ? atoi(stg) : 1;
+  const int stagger = stg ? atoi(stg) : 0;
   // launch order: only worth it when some CU gets more than one job (NEMO_SOLVE_ORDER=0 turns it off)
   const char *ord = getenv("NEMO_SOLVE_ORDER");
   const int32_t *d_order = nullptr;

@@ -426,6 +426,31 @@ def test_full_size_properties():
     assert np.abs(C - res.campos.cpu().numpy()).max() < 1e-4
 
 
+def test_solve_launch_order_is_invisible():
+    """Batches of more than 64 jobs are launched longest job first (solve_cost_kernel / solve_order_kernel):
+    scheduling only -- poses, losses and traces are bit-identical to the same jobs solved in small,
+    unordered batches, and the 6-DoF entry point behaves the same."""
+    from nemo_amd.pose_solver import SolverConfig
+    from nemo_amd.workloads import twelve_class_workload
+    wl = twelve_class_workload(80, seed=7, cfg=SolverConfig(total_epochs=40))
+    s, eng = wl.solver, wl.solver.engine
+    clu = eng.clutter_score(wl.feats, wl.clutter)
+    C0, th0, _, _ = eng.grid_search(wl.feats, clu, s.grid_C, s.grid_theta, mesh_idx=wl.mesh_idx, grid_idx=wl.mesh_idx)
+    pose, loss, trace = eng.solve(wl.feats, clu, C0, th0, mesh_idx=wl.mesh_idx, want_trace=True)   # ordered launch
+    tr0 = torch.zeros(80, 2, device='cuda')
+    pose6, loss6 = eng.solve6(wl.feats, clu, C0, th0, tr0, mesh_idx=wl.mesh_idx)
+    for lo in (0, 40):
+        idx = torch.arange(lo, lo + 40, dtype=torch.int32, device='cuda')
+        sl = slice(lo, lo + 40)
+        p, l, t = eng.solve(wl.feats, clu, C0[sl].contiguous(), th0[sl].contiguous(), img_idx=idx,
+                            mesh_idx=wl.mesh_idx[sl].contiguous(), want_trace=True)
+        assert torch.equal(p, pose[sl]) and torch.equal(l, loss[sl]) and torch.equal(t, trace[sl])
+        p6, l6 = eng.solve6(wl.feats, clu, C0[sl].contiguous(), th0[sl].contiguous(), tr0[sl].contiguous(), img_idx=idx,
+                            mesh_idx=wl.mesh_idx[sl].contiguous())
+        assert torch.equal(p6, pose6[sl]) and torch.equal(l6, loss6[sl])
+    assert torch.isfinite(pose).all() and len(torch.unique(wl.mesh_idx)) > 1
+
+
 def test_full_size_final_pose_statistics(oracle):
     """BASELINE size, free-running GPU solve vs free-running oracle from the same grid start:
     final poses within 0.5 degrees (north_star) for the large majority of images."""

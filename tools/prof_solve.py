@@ -55,6 +55,7 @@ if os.environ.get('NEMO_HIP_LIB'):
         per = 1.0 / (args.images * args.steps)
         print('wave-0 us per job-step (100 MHz wall clock): ' + ', '.join(f'{n} {st[i]*per/100:.2f}' for i, n in enumerate(names)) +
               f', phaseA {st[8]*per/100:.2f}, phaseB {st[9]*per/100:.2f}')
+        print(f'all waves, us per job-step: score loop busy {st[11]*per/100/16:.2f} (mean over 16 waves), wait at the band barrier {st[10]*per/100/16:.2f}')
 if args.grid:
     s.prerender()
     for r in range(args.reps):
