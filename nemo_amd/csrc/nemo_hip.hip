@@ -496,7 +496,7 @@ __device__ __forceinline__ float block_total(const Lds &L, int i) { return L.ust
 // `feat` is the image feature map and the loss of MeshPoseSolveAll.py:58-59 is used.
 template <int D, bool PERSP, bool GRAD, bool SCORE, bool RAW = false, bool PRE = false, bool BIG = false>
 __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, const float *__restrict__ feat,
-                          const float *__restrict__ clu, EmitOut emit) {
+                          const float *__restrict__ clu, EmitOut emit, bool zb_clean = false) {
 #ifndef NEMO_KIT
 #define NEMO_KIT 2
 #endif
@@ -948,9 +948,11 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
     for (int bb = b_lo; bb <= b_hi; bb += rows_per_band) {
       const int nr = min(rows_per_band, b_hi - bb + 1);
       const int npx = nr * bw;
-      // ---- 2a. clear the band's z-buffer
-      for (int i = tid; i < npx; i += NT) L.zb[i] = ~0ull;
-      __syncthreads();
+      // ---- 2a. clear the band's z-buffer (zb_clean: the caller left all `cap` keys cleared behind a barrier)
+      if (!(zb_clean && bb == b_lo)) {
+        for (int i = tid; i < npx; i += NT) L.zb[i] = ~0ull;
+        __syncthreads();
+      }
       STAMP(1);
       // ---- 2b. face-parallel rasterisation (one thread per face).  The candidate pixel centres of a face
       // (its exact bounding-box ranges) are walked as ONE flat loop, so a wave runs max-over-lanes of the
@@ -1503,6 +1505,118 @@ __global__ __launch_bounds__(1024) void grid_mfma_kernel(int hw, int N, int G, i
   }
 }
 
+// The same contraction with both operands staged through LDS.  Per pixel the workgroup needs the feature rows
+// of the pass's jobs (A, JTW tiles of 32 rows) and the rendered rows of its poses (B, PTW tiles of 32 rows): each
+// row is read from HBM once, coalesced, by the whole workgroup (one pixel ahead, through registers) instead of
+// once per wave with 16-byte gathers, and wave w multiplies tile (jt, pt) = (w / PTW, w % PTW) out of LDS.  Rows
+// are padded to 132 floats, which makes the 16-byte operand reads of a 16-lane group conflict-free.  For
+// D = 256 a pixel is staged in two halves of 128 features; the k-order of the FMA chains is that of
+// grid_mfma_kernel, so the partial sums are bit-identical to it.
+constexpr int GQ_ROW = 132;
+template <int D>
+__global__ __launch_bounds__(1024) void grid_mfma_lds_kernel(int hw, int N, int G, int n_chunks, int PTW, int JTW,
+                                                             const int32_t *img_idx, const int32_t *order,
+                                                             const int32_t *slot_start, const float *__restrict__ feat,
+                                                             const float *__restrict__ clu,
+                                                             const float *__restrict__ maps, float *__restrict__ partial,
+                                                             int clutter_on) {
+  extern __shared__ __align__(16) float gq_sm[];
+  constexpr int KH = D / 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, half = lane >> 5;
+  const int sl = blockIdx.x / n_chunks, c = blockIdx.x % n_chunks;
+  const int js = slot_start[sl], ns = slot_start[sl + 1] - js;
+  if (ns == 0) return;
+  const int p0 = c * GP_PIX, np = min(GP_PIX, hw - p0);
+  const int g0 = (int)blockIdx.y * PTW * 32;
+  const int nrowsA = JTW * 32, NS = PTW + JTW;  // slab k of 32 rows: A for k < JTW, B after
+  float *As = gq_sm, *Bs = gq_sm + nrowsA * GQ_ROW, *cls = gq_sm + NS * 32 * GQ_ROW;
+  const int pt = wave % PTW, jt = wave / PTW;
+  const bool active = jt < JTW;
+  const int srow = tid >> 5, sc4 = tid & 31;  // staging: row within the slab, 16-byte column
+  for (int tg = 0; tg < ns; tg += nrowsA) {
+    const float *rp[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      rp[k] = nullptr;
+      if (k < JTW) {
+        const int job = order[js + min(tg + k * 32 + srow, ns - 1)];
+        const int img = img_idx ? img_idx[job] : job;
+        rp[k] = feat + ((size_t)img * hw + p0) * D + sc4 * 4;
+      } else if (k < NS) {
+        const int g = min(g0 + (k - JTW) * 32 + srow, G - 1);
+        rp[k] = maps + (((size_t)sl * G + g) * hw + p0) * D + sc4 * 4;
+      }
+    }
+    const float *clp = nullptr;
+    if (clutter_on && tid < nrowsA) {
+      const int job = order[js + min(tg + tid, ns - 1)];
+      clp = clu + (size_t)(img_idx ? img_idx[job] : job) * hw + p0;
+    }
+    f16v lsum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lsum[r] = 0.0f;
+    f4 st[8];
+    float clv = 0.0f;
+    auto fetch = [&](int p, int kh) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k < NS) st[k] = __builtin_nontemporal_load((const f4 *)(rp[k] + (size_t)p * D + kh * 128));
+      if (kh == 0 && clp) clv = clp[p];
+    };
+    fetch(0, 0);
+    for (int p = 0; p < np; ++p) {
+      f16v acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+      for (int kh = 0; kh < KH; ++kh) {
+        __syncthreads();  // the previous stage has been consumed
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k < NS) *(f4 *)&gq_sm[(k * 32 + srow) * GQ_ROW + sc4 * 4] = st[k];
+        if (kh == 0 && tid < nrowsA) cls[tid] = clv;
+        __syncthreads();
+        if (kh + 1 < KH) fetch(p, kh + 1);
+        else if (p + 1 < np) fetch(p + 1, 0);
+        if (active) {
+          const float *ap = As + (jt * 32 + i) * GQ_ROW + 4 * half, *bp = Bs + (pt * 32 + i) * GQ_ROW + 4 * half;
+#pragma unroll 4
+          for (int q = 0; q < 16; ++q) {
+            const f4 a = *(const f4 *)(ap + 8 * q), b = *(const f4 *)(bp + 8 * q);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+          }
+        }
+      }
+      // C/D layout: column = lane & 31 (pose), row = (r & 3) + 8 * (r >> 2) + 4 * half (job of the tile)
+      if (active) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const f4 cv = *(const f4 *)&cls[jt * 32 + 8 * k + 4 * half];
+          const float cc[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float o = acc[4 * k + r];
+            lsum[4 * k + r] += clutter_on ? (fmaxf(o, cc[r]) - fmaxf(0.0f, cc[r])) : o;
+          }
+        }
+      }
+    }
+    if (active) {
+      const int g = g0 + pt * 32 + i;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int jrow = tg + jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (jrow < ns && g < G) partial[((size_t)c * N + order[js + jrow]) * G + g] = lsum[r];
+      }
+    }
+    __syncthreads();  // the next pass restages the LDS
+  }
+}
+
 // loss[n][g] = K_n - (1/hw) * sum over chunks (chunk order), K_n = 1 + mean(min(clu, 0)) (loss_constant).
 __global__ __launch_bounds__(256) void grid_finish_kernel(int hw, float inv_hw, int N, int G, int n_chunks,
                                                           const int32_t *img_idx, const int32_t *job_slot,
@@ -1745,8 +1859,12 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
   EmitOut none{nullptr, nullptr, nullptr};
   float last_loss = 0.f;
   u64 cov_total = 0;
+  // The z-buffer of the next step is cleared while thread 0 runs the serial camera / Adam section.
+  for (int i = threadIdx.x; i < P.cap; i += NT) L.zb[i] = ~0ull;
+  __syncthreads();
   for (int t = 0; t < steps; ++t) {
-    eval_pose<D, PERSP, true, true, false, false, BIG>(P, L, M, f, c, none);
+    eval_pose<D, PERSP, true, true, false, false, BIG>(P, L, M, f, c, none, true);
+    for (int i = threadIdx.x; i < P.cap; i += NT) L.zb[i] = ~0ull;
 #ifdef NEMO_STAMPS
     const unsigned long long st_lead = (threadIdx.x == 0) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 #endif
@@ -2077,6 +2195,7 @@ int nemo_ctx_create(const nemo_config *cfg, nemo_ctx **out) {
   SET_LDS_B(raster_kernel, false); SET_LDS_B(raster_kernel, true);
   SET_LDS_B(prerender_kernel, false); SET_LDS_B(prerender_kernel, true);
   SET_LDS_B(solve_cost_kernel, false); SET_LDS_B(solve_cost_kernel, true);
+  SET_LDS(grid_mfma_lds_kernel<128>); SET_LDS(grid_mfma_lds_kernel<256>);
   SET_LDS_B(score_kernel, 128, false); SET_LDS_B(score_kernel, 128, true);
   SET_LDS_B(score_kernel, 256, false); SET_LDS_B(score_kernel, 256, true);
   SET_LDS_B(grid_kernel, 128, false); SET_LDS_B(grid_kernel, 128, true);
@@ -2232,15 +2351,30 @@ int nemo_grid_search(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const i
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(grid_group_kernel, dim3(1), dim3(1024), 0, st, N, d_mesh_idx, d_grid_idx, ctx->d_pre_slot,
                        ctx->pre_pairs, ctx->d_gs_order, ctx->d_gs_start, ctx->d_gs_jobslot);
-    const int gy = (G + 511) / 512;  // poses beyond 512 go to further workgroups (grid.y)
-    const dim3 grd((unsigned)(ctx->pre_pairs * n_chunks), (unsigned)gy), blk((unsigned)(64 * (((G < 512 ? G : 512) + 31) / 32)));
     const int con = (ctx->cfg.clutter && d_clu) ? 1 : 0;
-    if (ctx->cfg.feat_dim == 128)
-      hipLaunchKernelGGL((grid_mfma_kernel<128>), grd, blk, 0, st, hw, N, G, n_chunks, d_img_idx, ctx->d_gs_order,
-                         ctx->d_gs_start, d_feat, d_clu, ctx->d_pre_maps, ctx->d_gs_partial, con);
-    else
-      hipLaunchKernelGGL((grid_mfma_kernel<256>), grd, blk, 0, st, hw, N, G, n_chunks, d_img_idx, ctx->d_gs_order,
-                         ctx->d_gs_start, d_feat, d_clu, ctx->d_pre_maps, ctx->d_gs_partial, con);
+    const char *old_k = getenv("NEMO_GRID_MFMA_DIRECT");
+    if (old_k && atoi(old_k)) {  // earlier variant: operands gathered straight from global memory by every wave
+      const int gy = (G + 511) / 512;  // poses beyond 512 go to further workgroups (grid.y)
+      const dim3 grd((unsigned)(ctx->pre_pairs * n_chunks), (unsigned)gy), blk((unsigned)(64 * (((G < 512 ? G : 512) + 31) / 32)));
+      if (ctx->cfg.feat_dim == 128)
+        hipLaunchKernelGGL((grid_mfma_kernel<128>), grd, blk, 0, st, hw, N, G, n_chunks, d_img_idx, ctx->d_gs_order,
+                           ctx->d_gs_start, d_feat, d_clu, ctx->d_pre_maps, ctx->d_gs_partial, con);
+      else
+        hipLaunchKernelGGL((grid_mfma_kernel<256>), grd, blk, 0, st, hw, N, G, n_chunks, d_img_idx, ctx->d_gs_order,
+                           ctx->d_gs_start, d_feat, d_clu, ctx->d_pre_maps, ctx->d_gs_partial, con);
+    } else {
+      // pose tiles per workgroup (PTW) and job tiles per pass (JTW): 16 waves, at most 8 staged tiles of 32 rows
+      const int PT = (G + 31) / 32, PTW = PT <= 5 ? PT : 4;
+      const int JTW = (16 / PTW) < (8 - PTW) ? (16 / PTW) : (8 - PTW);
+      const dim3 grd((unsigned)(ctx->pre_pairs * n_chunks), (unsigned)((PT + PTW - 1) / PTW)), blk(1024);
+      const size_t sm = ((size_t)(PTW + JTW) * 32 * GQ_ROW + (size_t)JTW * 32) * sizeof(float);
+      if (ctx->cfg.feat_dim == 128)
+        hipLaunchKernelGGL((grid_mfma_lds_kernel<128>), grd, blk, sm, st, hw, N, G, n_chunks, PTW, JTW, d_img_idx,
+                           ctx->d_gs_order, ctx->d_gs_start, d_feat, d_clu, ctx->d_pre_maps, ctx->d_gs_partial, con);
+      else
+        hipLaunchKernelGGL((grid_mfma_lds_kernel<256>), grd, blk, sm, st, hw, N, G, n_chunks, PTW, JTW, d_img_idx,
+                           ctx->d_gs_order, ctx->d_gs_start, d_feat, d_clu, ctx->d_pre_maps, ctx->d_gs_partial, con);
+    }
     hipLaunchKernelGGL(grid_finish_kernel, dim3(N), dim3(256), 0, st, hw, ctx->P.inv_hw, N, G, n_chunks, d_img_idx,
                        ctx->d_gs_jobslot, d_clu, ctx->d_gs_partial, ctx->d_pre_cnt, d_losses, ctx->d_counter, con);
     HIP_TRY(ctx, hipGetLastError());

@@ -194,3 +194,53 @@ def test_annotation_round_trip_and_rotation_error(tmp_path):
     assert records.rotation_error(a, 0.1, 0.2, 1.3, 5.0) < 1e-6
     assert abs(records.rotation_error(a, 0.1 + 0.05, 0.2, 1.3, 5.0) - 0.05) < 1e-6   # in-plane rotation only
     assert records.rotation_error(a, float('nan'), 0.2, 1.3, 5.0) == np.pi / 2          # :262-263
+
+
+def test_fastdiv_chain_is_correctly_rounded():
+    """csrc/fastdiv.h: r = fma(fma(-d, r0, 1), r0, r0); q0 = n r; q1 = fma(fma(-d, q0, n), r, q0);
+    q = fma(fma(-d, q1, n), r, q1) is the correctly rounded n / d when r0 is the correctly rounded
+    reciprocal, for operands in the range the kernel declares safe (exact rational arithmetic stands in
+    for the fused multiply-adds; corner mantissas included).  An arbitrary one-ulp-off r0 is NOT enough
+    (d = 2^k (1 - 2^-24) fails when r0 = 2^-k), so the guarantee on the device rests on v_rcp_f32 itself:
+    tools/fastdiv_check.hip compares the chain on the MI355X with the compiler's IEEE division and with the
+    quotient rounded from double precision, over 3.4e10 operand pairs."""
+    from fractions import Fraction
+
+    def rnd(x):  # Fraction -> nearest float32 (ties to even), normal range
+        if x == 0:
+            return np.float32(0.0)
+        sgn, ax = (-1, -x) if x < 0 else (1, x)
+        e = ax.numerator.bit_length() - ax.denominator.bit_length()
+        if Fraction(2) ** e > ax:
+            e -= 1
+        scaled = ax / Fraction(2) ** (e - 23)           # in [2^23, 2^24)
+        n, rem = divmod(scaled.numerator, scaled.denominator)
+        twice = 2 * rem
+        if twice > scaled.denominator or (twice == scaled.denominator and (n & 1)):
+            n += 1
+        return np.float32(sgn * float(n) * 2.0 ** (e - 23))
+
+    def fma(a, b, c):
+        return rnd(Fraction(float(a)) * Fraction(float(b)) + Fraction(float(c)))
+
+    rng = np.random.default_rng(11)
+    corner = [0, 0x7fffff, 0x400000, 0x3fffff, 0x400001, 1]
+
+    def make(k):
+        man = rng.integers(0, 1 << 23, k)
+        pick = rng.integers(0, 4, k) == 0
+        man[pick] = rng.choice(corner, pick.sum())
+        ex = rng.integers(127 - 40, 127 + 40, k)
+        sg = rng.integers(0, 2, k)
+        return ((sg << 31) | (ex << 23) | man).astype(np.uint32).view(np.float32)
+
+    bad = 0
+    for d in make(600):
+        r0 = rnd(Fraction(1) / Fraction(float(d)))
+        r = fma(fma(-d, r0, np.float32(1.0)), r0, r0)
+        for n in make(8):
+            q0 = rnd(Fraction(float(n)) * Fraction(float(r)))
+            q1 = fma(fma(-d, q0, n), r, q0)
+            q = fma(fma(-d, q1, n), r, q1)
+            bad += int(q != rnd(Fraction(float(n)) / Fraction(float(d))))
+    assert bad == 0

@@ -1,7 +1,8 @@
 // Checks FastDiv (nemo_amd/csrc/fastdiv.h) against the compiler's IEEE fp32 division on the GPU:
 // every thread walks a stream of (numerator, denominator) bit patterns inside the declared safe range
 // (random mantissas and exponents, plus the mantissa corner cases 0x000000, 0x7fffff, 0x400000 +- 1 for
-// either operand) and counts quotients that differ in any bit.  Prints the number of pairs and mismatches;
+// either operand) and counts quotients that differ in any bit from the compiler's division or from the
+// quotient computed in double precision and rounded to float.  Prints the number of pairs and mismatches;
 // exit status 1 on any mismatch.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o gpurun_out/fastdiv_check tools/fastdiv_check.hip
 #include <hip/hip_runtime.h>
@@ -48,8 +49,11 @@ __global__ void check(unsigned long long *bad, uint32_t seed, int inner, int den
       // half of the numerators are kept close to the denominator in magnitude (barycentric range)
       if (cn & 0x100u) n = __uint_as_float((__float_as_uint(n) & 0x807fffffu) | ((__float_as_uint(d) & 0x7f800000u) - (((cn >> 9) & 7u) << 23)));
       if (!FastDiv::in_range(__builtin_fabsf(n))) continue;
-      const float a = fd.div(n), b = n / d;
-      if (__float_as_uint(a) != __float_as_uint(b)) ++nbad;
+      // b: the compiler's IEEE expansion; c: the quotient rounded from double precision (53 >= 2 * 24 + 2
+      // bits, so the second rounding cannot change the result): an independent statement of the correctly
+      // rounded fp32 quotient
+      const float a = fd.div(n), b = n / d, c = (float)((double)n / (double)d);
+      if (__float_as_uint(a) != __float_as_uint(b) || __float_as_uint(a) != __float_as_uint(c)) ++nbad;
     }
   }
   if (nbad) atomicAdd(bad, nbad);
