@@ -61,7 +61,9 @@ const char *nemo_last_error(const nemo_ctx *ctx); /* ctx may be NULL (global slo
 /* Replaces MeshInterpolateModule.__init__ / update_memory (lib/MeshUtils.py:154-193):
  * registers one mesh (device pointers stay owned by the caller and must outlive
  * the context); the vertex bank f32[V][D] is indexed through faces instead of
- * materialising face_memory.  Returns the mesh id (>= 0) or an error. */
+ * materialising face_memory.  The faces are read once here (synchronous copy) to choose, per face, the
+ * order in which the score loop keeps its three bank rows in registers (a pure scheduling table of F bytes
+ * owned by the context; results do not depend on it).  Returns the mesh id (>= 0) or an error. */
 int nemo_mesh_register(nemo_ctx *ctx, const float *d_verts, int32_t V, const int32_t *d_faces,
                        int32_t F, const float *d_bank);
 

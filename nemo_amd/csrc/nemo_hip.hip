@@ -71,6 +71,10 @@ struct MeshDesc {
   const int32_t *faces;
   const float *bank;
   int32_t V, F;
+  // Per face, the order in which the score loop keeps the three bank rows in its registers: bits 2k..2k+1 = the
+  // vertex slot held by register set k (identity 0x24).  Chosen at registration so that consecutive faces keep as
+  // many rows in place as possible (the loop re-reads a row only when its register set changes vertex).
+  const uint8_t *slot_order;
 };
 
 struct KParams {
@@ -702,8 +706,11 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
           cls[u] = (P.clutter && clu) ? gclu[ent & 0xffffu] : 0.0f;
           if (u * 64 < cn) {
             const us4 fv_ = fc_at<BIG>(L, ent >> 16);
-            rec[u * 64 + lane] = uint4{(ent & 0xffffu) * (uint32_t)(D * 4), (uint32_t)fv_.x | ((uint32_t)fv_.y << 16),
-                                       (uint32_t)fv_.z, 0u};
+            // register set k of phase A holds the bank row of vertex slot (code >> 2k) & 3 (MeshDesc::slot_order)
+            const uint32_t code = fv_.w;
+            auto slot_id = [&](uint32_t c) { return (uint32_t)(c == 0 ? fv_.x : (c == 1 ? fv_.y : fv_.z)); };
+            rec[u * 64 + lane] = uint4{(ent & 0xffffu) * (uint32_t)(D * 4),
+                                       slot_id(code & 3u) | (slot_id((code >> 2) & 3u) << 16), slot_id((code >> 4) & 3u), code};
           }
         }
         // ---------------- phase A
@@ -765,11 +772,12 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
                 s0 += __shfl_xor(s0, 16); s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
               }
               const float w = sum3_row16(s0, s1, s2);  // quad q of the row holds the total of value q (q < 3)
-              if (el < cn && (gl & 3) == 0 && gl < 12) gbuf[3 * el + (gl >> 2)] = w;
+              // value q belongs to vertex slot (code >> 2q) & 3: phase B reads the hand-off buffer in slot order
+              if (el < cn && (gl & 3) == 0 && gl < 12) gbuf[3 * el + ((R0.w >> ((gl >> 2) * 2)) & 3u)] = w;
             } else {
               const float g0 = sum8(s0), g1 = sum8(s1), g2 = sum8(s2);
               if (gl == 0 && el < cn) {
-                gbuf[3 * el] = g0; gbuf[3 * el + 1] = g1; gbuf[3 * el + 2] = g2;
+                gbuf[3 * el + (R0.w & 3u)] = g0; gbuf[3 * el + ((R0.w >> 2) & 3u)] = g1; gbuf[3 * el + ((R0.w >> 4) & 3u)] = g2;
               }
             }
             R0 = R1; R1 = R2;
@@ -1179,8 +1187,10 @@ template <bool BIG>
 __device__ __forceinline__ void load_world_verts(const KParams &P, const Lds &L, const MeshDesc &M) {
   const gi32p gf = as_global(M.faces);
   const gf32p gv = as_global(M.verts);
+  const uint8_t GAS *so = as_global(M.slot_order);
   for (int i = threadIdx.x; i < M.F; i += NT)
-    fc_put<BIG>(L, i, us4{(unsigned short)gf[3 * i], (unsigned short)gf[3 * i + 1], (unsigned short)gf[3 * i + 2], 0});
+    fc_put<BIG>(L, i, us4{(unsigned short)gf[3 * i], (unsigned short)gf[3 * i + 1], (unsigned short)gf[3 * i + 2],
+                          (unsigned short)(M.slot_order ? so[i] : 0x24)});
   for (int i = (int)threadIdx.x - 2; i < P.S + 2; i += NT) L.ndc[i] = ndc_of(i, (float)P.S);
   __syncthreads();
 }
@@ -2034,6 +2044,7 @@ struct nemo_ctx {
   int32_t *d_gs_order, *d_gs_start, *d_gs_jobslot;
   float *d_gs_partial;
   size_t gs_jobs_cap, gs_partial_cap;
+  uint8_t *d_slot_order[MAX_MESHES];  // per mesh (MeshDesc::slot_order), owned by the context
   unsigned char *d_big;  // BIG-mesh table scratch
   size_t big_cap;
   int32_t *d_so;         // solve launch order workspace: cost[so_cap], order[so_cap]
@@ -2218,6 +2229,7 @@ int nemo_ctx_destroy(nemo_ctx *ctx) {
   hipFree(ctx->d_pre_slot); hipFree(ctx->d_pre_cnt); hipFree(ctx->d_pre_pairs); hipFree(ctx->d_pre_list);
   hipFree(ctx->d_pre_maps); hipFree(ctx->d_gs_order); hipFree(ctx->d_gs_start); hipFree(ctx->d_gs_jobslot);
   hipFree(ctx->d_gs_partial); hipFree(ctx->d_big); hipFree(ctx->d_so);
+  for (int i = 0; i < ctx->n_meshes; ++i) hipFree(ctx->d_slot_order[i]);
   delete ctx;
   return NEMO_OK;
 }
@@ -2236,8 +2248,34 @@ int nemo_mesh_register(nemo_ctx *ctx, const float *d_verts, int32_t V, const int
   int rc = plan_lds(ctx);
   if (rc != NEMO_OK) { ctx->vmax_seen = old_vmax; ctx->fmax_seen = old_fmax; plan_lds(ctx); return rc; }
   const int id = ctx->n_meshes;
-  ctx->h_meshes[id] = MeshDesc{d_verts, d_faces, d_bank, V, F};
-  HIP_TRY(ctx, hipMemcpy(ctx->d_meshes + id, &ctx->h_meshes[id], sizeof(MeshDesc), hipMemcpyHostToDevice));
+  // Slot order (MeshDesc::slot_order): walk the faces in index order -- the order of the score loop's face-major
+  // list -- and give every face the permutation of its three vertices that leaves the most register sets of the
+  // previous face untouched.  Results do not depend on it (the dot products are stored back by vertex slot).
+  std::vector<int32_t> hf((size_t)3 * F);
+  HIP_TRY(ctx, hipMemcpy(hf.data(), d_faces, sizeof(int32_t) * 3 * (size_t)F, hipMemcpyDeviceToHost));
+  std::vector<uint8_t> order((size_t)F);
+  {
+    static const int perms[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+    int32_t prev[3] = {-1, -1, -1};
+    for (int f = 0; f < F; ++f) {
+      const int32_t *t = &hf[(size_t)3 * f];
+      int best = -1, bp = 0;
+      for (int p = 0; p < 6; ++p) {
+        const int m = (t[perms[p][0]] == prev[0]) + (t[perms[p][1]] == prev[1]) + (t[perms[p][2]] == prev[2]);
+        if (m > best) { best = m; bp = p; }
+      }
+      for (int k = 0; k < 3; ++k) prev[k] = t[perms[bp][k]];
+      order[f] = (uint8_t)(perms[bp][0] | (perms[bp][1] << 2) | (perms[bp][2] << 4));
+    }
+  }
+  uint8_t *d_order = nullptr;
+  HIP_TRY(ctx, hipMalloc((void **)&d_order, (size_t)F));
+  hipError_t ce = hipMemcpy(d_order, order.data(), (size_t)F, hipMemcpyHostToDevice);
+  if (ce != hipSuccess) { hipFree(d_order); return hip_fail(ctx, ce, "nemo_mesh_register: slot order upload"); }
+  ctx->d_slot_order[id] = d_order;
+  ctx->h_meshes[id] = MeshDesc{d_verts, d_faces, d_bank, V, F, d_order};
+  ce = hipMemcpy(ctx->d_meshes + id, &ctx->h_meshes[id], sizeof(MeshDesc), hipMemcpyHostToDevice);
+  if (ce != hipSuccess) { hipFree(d_order); ctx->d_slot_order[id] = nullptr; return hip_fail(ctx, ce, "nemo_mesh_register: descriptor upload"); }
   ctx->n_meshes = id + 1;
   return id;
 }
