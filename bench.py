@@ -47,21 +47,24 @@ def cpu_baseline(wl, n_sample):
     meshes = [(v.cpu().numpy(), f.cpu().numpy(), b.cpu().numpy()) for v, f, b in eng._keep]
     gC, gT = s.grid_C.cpu().numpy(), s.grid_theta.cpu().numpy()
     orc.lib()
+    cores = min(16, os.cpu_count() or 1, n_sample)
     out = [None] * n_sample
 
-    def work(i):
-        v, f, b = meshes[mesh[i]]
-        out[i] = orc.solve_batch(cfg, v, f, b, feats[i:i + 1], cvec, gC[mesh[i]], gT[mesh[i]], tab,
-                                 s.cfg.adam_beta_0, s.cfg.adam_beta_1, s.cfg.adam_eps, nthreads=1)
+    def work(k):  # worker k takes images k, k + cores, ...
+        for i in range(k, n_sample, cores):
+            v, f, b = meshes[mesh[i]]
+            out[i] = orc.solve_batch(cfg, v, f, b, feats[i:i + 1], cvec, gC[mesh[i]], gT[mesh[i]], tab,
+                                     s.cfg.adam_beta_0, s.cfg.adam_beta_1, s.cfg.adam_eps, nthreads=1)
 
     t0 = time.perf_counter()
-    th = [threading.Thread(target=work, args=(i,)) for i in range(n_sample)]
+    th = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
     [t.start() for t in th]
     [t.join() for t in th]
     dt = time.perf_counter() - t0
-    return {'value': n_sample / dt, 'unit': 'solves/s', 'cores': n_sample, 'kind': 'port',
+    return {'value': n_sample / dt, 'unit': 'solves/s', 'cores': cores, 'kind': 'port',
             'sample': f'{n_sample} images of the same workload (144-pose init + {s.cfg.total_epochs} Adam steps each), '
-                      f'one per host thread, {dt:.1f} s wall; host has {os.cpu_count()} logical CPUs'}
+                      f'{cores} host threads (the oracle is single-threaded per image; ctypes releases the GIL), '
+                      f'{dt:.1f} s wall; host has {os.cpu_count()} logical CPUs'}
 
 
 def pmc_traffic(cov_steps):
@@ -85,7 +88,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--images', type=int, default=1024, help='images per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=0, help='images in the CPU baseline sample (0 = min(16, cores))')
+    ap.add_argument('--cpu-sample', type=int, default=0, help='images in the CPU baseline sample (0 = 3 per host thread, at most 16 threads: about 13 s)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -182,7 +185,7 @@ def main():
             'quality': {'finite_fraction': ok, 'median_err_deg_vs_synthetic_gt': float(np.degrees(np.median(errs)))},
         }
         if world == 1 and not args.no_cpu_baseline:
-            n_sample = args.cpu_sample or min(16, os.cpu_count() or 1)
+            n_sample = args.cpu_sample or 3 * min(16, os.cpu_count() or 1)
             out['cpu_baseline'] = cpu_baseline(wl, n_sample)
         print(json.dumps(out), flush=True)
     if world > 1:
