@@ -839,7 +839,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
     }
 #endif
     if (SCORE) {
-      // chunk partials -> running totals, in chunk order, one lane per total (wave 0 owns U_TOT)
+      // the waves' partials -> running totals, in wave order, one lane per total (wave 0 owns U_TOT)
       constexpr int NPB = GRAD ? 13 : 1;
       if (wave == 0 && lane < NPB) {
         const float *part = (const float *)L.zb;
@@ -1050,7 +1050,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
     }
   }
 
-  // ---- 4. totals are already in L.ust[U_TOT..] (chunk partials added in chunk order by wave 0)
+  // ---- 4. totals are already in L.ust[U_TOT..] (the waves' partials added in wave order by wave 0)
   if (tid == 0) {
     L.ust[U_TOT + T_NCOV] = (float)ncov;
     if (GRAD) {  // dL/dR = R * sum((view - T)^T q)
@@ -2171,6 +2171,8 @@ int nemo_mesh_register(nemo_ctx *ctx, const float *d_verts, int32_t V, const int
   {
     static const int perms[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
     int32_t prev[3] = {-1, -1, -1};
+    const char *so_env = getenv("NEMO_SLOT_ORDER");
+    const bool identity = so_env && atoi(so_env) == 0;  // experiments / invariance test: every face keeps its own order
     for (int f = 0; f < F; ++f) {
       const int32_t *t = &hf[(size_t)3 * f];
       int best = -1, bp = 0;
@@ -2178,6 +2180,7 @@ int nemo_mesh_register(nemo_ctx *ctx, const float *d_verts, int32_t V, const int
         const int m = (t[perms[p][0]] == prev[0]) + (t[perms[p][1]] == prev[1]) + (t[perms[p][2]] == prev[2]);
         if (m > best) { best = m; bp = p; }
       }
+      if (identity) bp = 0;
       for (int k = 0; k < 3; ++k) prev[k] = t[perms[bp][k]];
       order[f] = (uint8_t)(perms[bp][0] | (perms[bp][1] << 2) | (perms[bp][2] << 4));
     }

@@ -451,6 +451,28 @@ def test_solve_launch_order_is_invisible():
     assert torch.isfinite(pose).all() and len(torch.unique(wl.mesh_idx)) > 1
 
 
+def test_bank_row_slot_order_is_invisible(monkeypatch):
+    """nemo_mesh_register chooses, per face, which register set of the score loop holds which vertex's bank row
+    (fewer re-reads between neighbouring faces).  Scheduling only: the dot products are stored back by vertex
+    slot, so losses, gradients and whole solves are bit-identical to meshes registered in face order."""
+    from nemo_amd.pose_solver import SolverConfig
+    from nemo_amd.workloads import twelve_class_workload
+    out = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('NEMO_SLOT_ORDER', flag)
+        wl = twelve_class_workload(24, seed=11, cfg=SolverConfig(total_epochs=30))
+        s, eng = wl.solver, wl.solver.engine
+        clu = eng.clutter_score(wl.feats, wl.clutter)
+        C0, th0, best, losses = eng.grid_search(wl.feats, clu, s.grid_C, s.grid_theta, mesh_idx=wl.mesh_idx, grid_idx=wl.mesh_idx)
+        loss, grad, ncov = eng.score_fwd_bwd(wl.feats, clu, C0, th0, mesh_idx=wl.mesh_idx)
+        pose, fl, trace = eng.solve(wl.feats, clu, C0, th0, mesh_idx=wl.mesh_idx, want_trace=True)
+        out.append([t.clone() for t in (wl.feats, losses, loss, grad, ncov, pose, fl, trace)])
+    assert torch.equal(out[0][0], out[1][0])  # same synthetic workload both times
+    for a, b in zip(out[0][1:], out[1][1:]):
+        assert torch.equal(a, b)
+    assert (out[0][4] > 0).all()
+
+
 def test_full_size_final_pose_statistics(oracle):
     """BASELINE size, free-running GPU solve vs free-running oracle from the same grid start:
     final poses within 0.5 degrees (north_star) for the large majority of images."""
