@@ -430,7 +430,7 @@ template <bool BIG> __device__ __forceinline__ void finfo_put_mask(const Lds &L,
   if constexpr (BIG) *((__attribute__((address_space(1))) u2v *)(L.gfinfo + i) + 1) = v; else *((u2v *)(L.finfo + i) + 1) = v;
 }
 
-constexpr int MAX_GRIDS = 64;
+constexpr int MAX_GRIDS = 128;  // pose grids per context (MultiCuboid: one per subtype mesh, 79 in all)
 constexpr int GRID_POSES_PER_WG = 4;
 struct PreStore {  // pre-rendered grid poses (device pointers; slot == nullptr: none)
   const int32_t *slot;   // [MAX_MESHES][MAX_GRIDS] -> pair slot or -1
