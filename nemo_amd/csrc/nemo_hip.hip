@@ -351,6 +351,7 @@ __device__ __forceinline__ float wave_max(float v) {
 #endif
 #ifdef NEMO_STAMPS
 __device__ unsigned long long g_stamps[16];
+__device__ unsigned long long g_wave_busy[16];  // score-loop busy time by wave index
 #define STAMP_DECL unsigned long long st_prev = (threadIdx.x == 0) ? __builtin_amdgcn_s_memrealtime() : 0ull
 #define STAMP(i)                                                         \
   do {                                                                   \
@@ -836,6 +837,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
     if (SCORE && (threadIdx.x & 63) == 0) {  // every wave: its wait at the band barrier, and its busy time in the score loop
       atomicAdd(&g_stamps[10], __builtin_amdgcn_s_memrealtime() - st_arrive);
       atomicAdd(&g_stamps[11], st_arrive - st_score0);
+      atomicAdd(&g_wave_busy[(threadIdx.x >> 6) & 15], st_arrive - st_score0);
     }
 #endif
     if (SCORE) {
@@ -2559,6 +2561,17 @@ int nemo_debug_stamps(unsigned long long *out16) {
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
   unsigned long long z[16] = {0};
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -1;
+  return 0;
+}
+#endif
+
+#ifdef NEMO_STAMPS
+// diagnostic build only: read (and clear) the score-loop busy time summed per wave index
+int nemo_debug_wave_busy(unsigned long long *out16) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_wave_busy), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  unsigned long long z[16] = {0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_wave_busy), z, sizeof(z)) != hipSuccess) return -1;
   return 0;
 }
 #endif

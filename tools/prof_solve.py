@@ -56,6 +56,11 @@ if os.environ.get('NEMO_HIP_LIB'):
         print('wave-0 us per job-step (100 MHz wall clock): ' + ', '.join(f'{n} {st[i]*per/100:.2f}' for i, n in enumerate(names)) +
               f', phaseA {st[8]*per/100:.2f}, phaseB {st[9]*per/100:.2f}')
         print(f'all waves, us per job-step: score loop busy {st[11]*per/100/16:.2f} (mean over 16 waves), wait at the band barrier {st[10]*per/100/16:.2f}')
+    wb = (ctypes.c_ulonglong * 16)()
+    if hasattr(eng.lib, 'nemo_debug_wave_busy') and eng.lib.nemo_debug_wave_busy(wb) == 0 and sum(wb):
+        m = sum(wb) / 16.0
+        print('score-loop busy time by wave index, relative to the mean (all solves since the last read): ' +
+              ' '.join(f'{x / m:.3f}' for x in wb))
 if args.grid:
     s.prerender()
     for r in range(args.reps):
