@@ -36,9 +36,6 @@ namespace {
 #define NEMO_NT 1024
 #endif
 constexpr int NT = NEMO_NT;    // threads per workgroup of the pose kernels
-#ifndef NEMO_WPE
-#define NEMO_WPE ((NEMO_NT + 255) / 256)  // waves per SIMD of one workgroup: bounds the VGPR budget (512 / NEMO_WPE)
-#endif
 constexpr int NW = NT / 64;    // waves per workgroup
 constexpr int RED_N = 16;      // floats per wave in the reduction scratch
 #ifndef NEMO_CHUNK
@@ -46,9 +43,9 @@ constexpr int RED_N = 16;      // floats per wave in the reduction scratch
 #endif
 constexpr int CH = NEMO_CHUNK;  // covered pixels per score chunk (multiple of 64)
 constexpr int UST_N = 96;      // floats of workgroup-uniform state kept in LDS
-// uniform-state slots: R[0..8] T[9..11] p[12..15] m[16..19] v[20..23] K[24], block totals [32..45],
+// uniform-state slots: R[0..8] T[9..11] p[12..15] m[16..19] v[20..23] K[24], chunk counter [25], block totals [32..45],
 // camera intermediates of the current iterate [48..82] (kept for the camera backward)
-constexpr int U_R = 0, U_T = 9, U_P = 12, U_M = 16, U_V = 20, U_K = 24, U_TOT = 32, U_CAM = 48;
+constexpr int U_R = 0, U_T = 9, U_P = 12, U_M = 16, U_V = 20, U_K = 24, U_CTR = 25, U_TOT = 32, U_CAM = 48;
 constexpr int U_P6 = 84, U_M6 = 86, U_V6 = 88;  // 6-DoF variant: trans_2d and its Adam moments
 // block totals: [0] loss term, [1..9] dL/dR, [10..12] dL/dT, [13] covered pixels
 constexpr int T_LOSS = 0, T_GR = 1, T_GT = 10, T_NCOV = 13;
@@ -343,6 +340,9 @@ __device__ __forceinline__ float wave_max(float v) {
 // Diagnostic build only (-DNEMO_STAMPS): wave 0 / lane 0 of every workgroup adds the
 // cycles it spent per phase (barrier waits included) into g_stamps; the shipped
 // library contains none of this.
+#ifndef NEMO_SEG
+#define NEMO_SEG 1  // 1: static wave-contiguous score segments, one reduction per wave; 0: dynamic guided chunks
+#endif
 #ifndef NEMO_RABL
 #define NEMO_RABL 0  // rasteriser ablations (diagnostic builds): 1 = no candidate loop, 2 = candidates never accepted
 #endif
@@ -387,11 +387,44 @@ struct Lds {
   float *ust;            // [UST_N] workgroup-uniform state (camera, Adam)
 };
 
-// Score-phase scratch hosted by the dead z-buffer: [NW][16] per-wave partial sums, [NW][CH] per-entry records (16 B),
-// [NW][CH][3] dot products handed from phase A to phase B.
-constexpr int PART_FLOATS = NW * 16;
+// Score chunks come in guided sizes: CH entries for the bulk of the face-major list, then CH_MID, then
+// CH_SMALL for the last NW*CH_SMALL entries, so that the waves run out of work within a few pixels of each other.
+// The plan is a function of the list length only (the chunk-order sum stays deterministic).
+struct ChunkPlan {
+  int n_big, n_mid, b_mid, b_small, nchunks;
+};
+__host__ __device__ inline int max_chunks(int cap) { return cap / CH + 2 * NW + 24; }
+#ifndef NEMO_CHUNK_MID
+#define NEMO_CHUNK_MID 64
+#endif
+#ifndef NEMO_CHUNK_SMALL
+#define NEMO_CHUNK_SMALL 32
+#endif
+constexpr int CH_MID = NEMO_CHUNK_MID < CH ? NEMO_CHUNK_MID : CH, CH_SMALL = NEMO_CHUNK_SMALL;
+__device__ __forceinline__ ChunkPlan plan_chunks(int ntot) {
+  ChunkPlan c;
+  const int bulk = max(0, ntot - NW * (CH_SMALL + CH_MID));
+  c.n_big = (bulk + CH - 1) / CH;
+  c.b_mid = c.n_big * CH;
+  const int mid = max(0, ntot - c.b_mid - NW * CH_SMALL);
+  c.n_mid = (mid + CH_MID - 1) / CH_MID;
+  c.b_small = c.b_mid + c.n_mid * CH_MID;
+  c.nchunks = c.n_big + c.n_mid + (max(0, ntot - c.b_small) + CH_SMALL - 1) / CH_SMALL;
+  return c;
+}
+__device__ __forceinline__ void chunk_range(const ChunkPlan &c, int ntot, int id, int &cb, int &cn) {
+  if (id < c.n_big) {
+    cb = id * CH; cn = CH;
+  } else if (id < c.n_big + c.n_mid) {
+    cb = c.b_mid + (id - c.n_big) * CH_MID; cn = CH_MID;
+  } else {
+    cb = c.b_small + (id - c.n_big - c.n_mid) * CH_SMALL; cn = CH_SMALL;
+  }
+  cn = min(cn, ntot - cb);
+}
+
 __host__ __device__ inline size_t zb_region_bytes(int cap) {
-  const size_t a = (size_t)cap * 8, b = (size_t)PART_FLOATS * 4 + (size_t)NW * CH * (12 + 16);
+  const size_t a = (size_t)cap * 8, b = (size_t)max_chunks(cap) * 64 + (size_t)NW * CH * (12 + 16);
   return ((a > b ? a : b) + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t lds_bytes(int cap, int vmax, int fmax, int wmax, int S) {
@@ -486,6 +519,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
 
   STAMP_DECL;
   if (tid < 16) L.ust[U_TOT + tid] = 0.0f;  // ordered before any use by the bounding-box barrier
+  if (tid == 16) *(int *)(L.ust + U_CTR) = 0;
   // ---- 1. project vertices (MeshRasterizer.transform; order fixed in DESIGN.md)
   float umin = 3.0e38f, umax = -3.0e38f, tmin = 3.0e38f, tmax = -3.0e38f;
   {
@@ -576,111 +610,146 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
         if (emit.zbuf) emit.zbuf[p] = fr.pz;
       }
     } else {
-      // ---- 3. fused interpolate + score (+ backward).  Wave w owns the contiguous entries
-      // [ntot w / NW, ntot (w + 1) / NW) of the face-major list; each of its GPW lane groups owns a contiguous
-      // quarter of them (its run) and the wave walks the GPW runs side by side, PER0 entries of each per chunk:
-      //  records (one lane per entry of the chunk): feature-row byte offset, the three bank rows and the slot
-      //    order of every entry, 64 entries per instruction, parked in LDS;
-      //  phase A (LPP lanes per pixel): 16-byte loads of the pixel's feature row and of the face's three
-      //    vertex-bank rows, three D-long dot products reduced with DPP, results parked in a wave-private LDS
-      //    buffer.  A lane group re-reads a bank row only when that register set changes vertex -- its run is
-      //    contiguous over the whole segment, so the rows carry over from chunk to chunk -- and the next
-      //    entry's feature row is always in flight (ping-pong registers; the prefetch is unconditional and
-      //    issued behind the conditional bank loads, so the in-order vmcnt wait for a bank row leaves it alone);
-      //  phase B (one lane per entry): barycentrics, object score, loss term and the hand-derived backward
-      //    to dL/dR, dL/dT accumulators, kept in registers across the wave's chunks.
-      // Both phases are wave-local (LDS operations of one wave complete in order), so there is no workgroup
-      // barrier inside the loop.  Each wave reduces its 13 sums once (fixed DPP tree) and leaves them in LDS
-      // (the z-buffer is dead by now and hosts them); they are added in wave order afterwards.  The split is a
-      // function of the list length only, so every sum is reproducible bit for bit.
+      // ---- 3. fused interpolate + score (+ backward).  Each wave owns a contiguous
+      // segment of the face-major list and works through it in chunks of 64 pixels:
+      //  phase A (LPP lanes per pixel): 16-byte loads of the pixel's feature row and of
+      //    the face's three vertex-bank rows, three D-long dot products reduced with
+      //    DPP, results parked in a wave-private LDS buffer.  A lane group walks
+      //    consecutive list entries and re-reads a bank row only when that vertex slot
+      //    changes (the two triangles of a cuboid cell share two of their three slots).
+      //    The next entry's feature row is always in flight (ping-pong registers); the
+      //    prefetch is unconditional because a conditional load would make the compiler
+      //    drain vmcnt to zero every iteration.
+      //  phase B (one lane per pixel): barycentrics, object score, loss term and the
+      //    hand-derived backward to dL/dR, dL/dT accumulators.
+      // Both phases are wave-local (LDS operations of one wave complete in order), so
+      // there is no workgroup barrier inside this loop.
+      // Chunks are handed out dynamically (LDS counter) so that no wave idles at the band barrier;
+      // every chunk leaves its 14 partial sums in LDS (the z-buffer is dead by now and hosts them)
+      // and they are added up in chunk order afterwards, so the totals do not depend on which
+      // wave ran which chunk.
       constexpr int GPW = 64 / LPP;
-      constexpr int PER0 = CH / GPW;     // entries of a run per chunk
-      constexpr int NP = GRAD ? 13 : 1;  // partials per wave: loss term, dL/dR (9), dL/dT (3)
+      constexpr int NP = GRAD ? 13 : 1;  // partials per chunk: loss term, dL/dR (9), dL/dT (3)
       const int gl = lane & (LPP - 1), grp = lane / LPP;
 #ifdef NEMO_STAMPS
       st_score0 = __builtin_amdgcn_s_memrealtime();
 #endif
-      float *part = (float *)L.zb;                                  // [NW][16]
-      uint4 *rec = (uint4 *)(part + PART_FLOATS) + wave * CH;                                   // [NW][CH]
-      float *gbuf = (float *)((uint4 *)(part + PART_FLOATS) + NW * CH) + wave * (CH * 3);       // [NW][CH*3]
+      const ChunkPlan cp = plan_chunks(ntot);
+      const int nchunks = cp.nchunks;
+      float *part = (float *)L.zb;                                  // [nchunks][16]
+      uint4 *rec = (uint4 *)(part + (size_t)max_chunks(P.cap) * 16) + wave * CH;               // [NW][CH]
+      float *gbuf = (float *)((uint4 *)(part + (size_t)max_chunks(P.cap) * 16) + NW * CH) + wave * (CH * 3);  // [NW][CH*3]
+      int *ctr = (int *)(L.ust + U_CTR);
+#ifdef NEMO_STATIC_CHUNKS
+      int static_next = wave;  // diagnostic build: round-robin static chunk assignment
+      auto grab = [&]() { const int v = static_next; static_next += NW; (void)ctr; return v; };
+#else
+      auto grab = [&]() {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(ctr, 1);
+        return __builtin_amdgcn_readfirstlane(v);
+      };
+#endif
       // rows are addressed as uniform base + 32-bit byte offset (feature window and bank are < 4 GiB)
       typedef const __attribute__((address_space(1))) char *gbytep;
       const gbytep fbytes = (gbytep)gfeat, bbytes = (gbytep)bank;
       const uint32_t gl16 = (uint32_t)gl * 16u;
+      // byte offset of the feature row of this lane group's first entry in the chunk [cb_, cb_ + cn_)
+      auto first_off_at = [&](int cb_, int cn_) {
+        const int per_ = (cn_ + GPW - 1) / GPW;
+        return (L.list[cb_ + min(grp * per_, cn_ - 1)] & 0xffffu) * (uint32_t)(D * 4) + gl16;
+      };
+      auto first_off = [&](int c) {
+        int cb_, cn_;
+        chunk_range(cp, ntot, c, cb_, cn_);
+        return first_off_at(cb_, cn_);
+      };
+      f4 xa[KIT], xb[KIT];  // ping-pong: current / next feature-row fragments
+#if NEMO_SEG
+      // Static split: wave w owns the contiguous entries [ntot w / NW, ntot (w + 1) / NW) and walks them in
+      // chunks of CH; its 13 sums stay in registers across chunks and are reduced across lanes once.
       const int seg_b = (ntot * wave) / NW, seg_e = (ntot * (wave + 1)) / NW;
-      const int Lq = (seg_e - seg_b + GPW - 1) / GPW;   // run length (the last runs may be shorter, or empty)
-      const int nch = (Lq + PER0 - 1) / PER0;
-      // list index of entry k of lane group g's run, clamped into the segment (clamped entries are loaded like
-      // any other and their results dropped)
-      auto run_idx = [&](int g, int k) { return min(seg_b + g * Lq + k, seg_e - 1); };
       float pl = 0.f;
       float GR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       float GT[3] = {0.f, 0.f, 0.f};
-      f4 xa[KIT], xb[KIT];  // ping-pong: current / next feature-row fragments
-      int i0 = -1, i1 = -1, i2 = -1;  // vertices whose bank rows y0..y2 hold
-      f4 y0[KIT], y1[KIT], y2[KIT];
-#pragma unroll
-      for (int k = 0; k < KIT; ++k) y0[k] = y1[k] = y2[k] = f4{0.f, 0.f, 0.f, 0.f};
-      if (nch > 0) {
-        const gf4p Fp = (gf4p)(fbytes + ((L.list[run_idx(grp, 0)] & 0xffffu) * (uint32_t)(D * 4) + gl16));
+      int cb = seg_b;
+      (void)first_off; (void)grab; (void)nchunks;
+      if (cb < seg_e) {
+        const gf4p Fp = (gf4p)(fbytes + first_off_at(cb, min(CH, seg_e - cb)));
 #pragma unroll
         for (int k = 0; k < KIT; ++k) xa[k] = __builtin_nontemporal_load(Fp + LPP * k);
       }
-      for (int c = 0; c < nch; ++c) {
-        const int k0 = c * PER0;                 // position of the chunk in every run
-        const int per = min(PER0, Lq - k0);      // entries per lane group in this chunk
+      while (cb < seg_e) {
+        const int cn = min(CH, seg_e - cb);
+        const int cb_next = cb + CH;
+#else
+      int ccur = grab(), cnxt = grab();
+      if (ccur < nchunks) {
+        const gf4p Fp = (gf4p)(fbytes + first_off(ccur));
+#pragma unroll
+        for (int k = 0; k < KIT; ++k) xa[k] = __builtin_nontemporal_load(Fp + LPP * k);
+      }
+      while (ccur < nchunks) {
+        int cb, cn;
+        chunk_range(cp, ntot, ccur, cb, cn);
+#endif
+        const int per = (cn + GPW - 1) / GPW;  // entries per lane group in this chunk
         // ---------------- records (one lane per entry): everything phase A needs to know about an entry
-        // -- feature-row byte offset, the three bank rows in register-set order -- is worked out once here
-        // instead of by every lane of a group inside the loop.  The same pass fetches this lane's phase-B
-        // list entries and clutter scores (they land during phase A).  Slot s = g * PER0 + k of the chunk
-        // is entry k0 + k of run g.
+        // -- feature-row byte offset and the three bank rows -- is worked out once here, 64 entries per
+        // instruction, instead of by every lane of a group inside the loop.  The same pass fetches this
+        // lane's phase-B list entries and clutter scores (they land during phase A).
         uint32_t ent_bs[CH / 64];
         float cls[CH / 64];
-        bool vld[CH / 64];
 #pragma unroll
         for (int u = 0; u < CH / 64; ++u) {
-          const int sl = u * 64 + lane, g = sl / PER0, k = k0 + (sl % PER0);
-          const int idx = seg_b + g * Lq + k;
-          vld[u] = k < Lq && idx < seg_e;
-          const uint32_t ent = L.list[min(idx, seg_e - 1)];
+          const uint32_t ent = L.list[cb + min(u * 64 + lane, cn - 1)];
           ent_bs[u] = ent;
           cls[u] = (P.clutter && clu) ? gclu[ent & 0xffffu] : 0.0f;
-          const us4 fv_ = fc_at<BIG>(L, ent >> 16);
-          // register set k of phase A holds the bank row of vertex slot (code >> 2k) & 3 (MeshDesc::slot_order)
-          const uint32_t code = fv_.w;
-          auto slot_id = [&](uint32_t q) { return (uint32_t)(q == 0 ? fv_.x : (q == 1 ? fv_.y : fv_.z)); };
-          rec[sl] = uint4{(ent & 0xffffu) * (uint32_t)(D * 4), slot_id(code & 3u) | (slot_id((code >> 2) & 3u) << 16),
-                          slot_id((code >> 4) & 3u), code | (vld[u] ? 0x100u : 0u)};
+          if (u * 64 < cn) {
+            const us4 fv_ = fc_at<BIG>(L, ent >> 16);
+            // register set k of phase A holds the bank row of vertex slot (code >> 2k) & 3 (MeshDesc::slot_order)
+            const uint32_t code = fv_.w;
+            auto slot_id = [&](uint32_t c) { return (uint32_t)(c == 0 ? fv_.x : (c == 1 ? fv_.y : fv_.z)); };
+            rec[u * 64 + lane] = uint4{(ent & 0xffffu) * (uint32_t)(D * 4),
+                                       slot_id(code & 3u) | (slot_id((code >> 2) & 3u) << 16), slot_id((code >> 4) & 3u), code};
+          }
         }
         // ---------------- phase A
         {
-          const int e0 = grp * PER0;
-          uint4 R0 = rec[e0], R1 = rec[e0 + min(1, per - 1)];  // records run two entries ahead
-          // first feature row of this group in the next chunk (or a harmless reload at the very end)
-          const uint32_t off_next_chunk = (c + 1 < nch) ? (L.list[run_idx(grp, k0 + PER0)] & 0xffffu) * (uint32_t)(D * 4) + gl16
-                                                        : R0.x + gl16;
+          // first feature row of this group in the wave's next chunk (or a harmless reload at the very end)
+          const int e0 = grp * per;
+          uint4 R0 = rec[min(e0, cn - 1)], R1 = rec[min(e0 + 1, cn - 1)];  // records run two entries ahead
+#if NEMO_SEG
+          const uint32_t off_next_chunk = cb_next < seg_e ? first_off_at(cb_next, min(CH, seg_e - cb_next)) : R0.x + gl16;
+#else
+          const uint32_t off_next_chunk = cnxt < nchunks ? first_off(cnxt) : R0.x + gl16;
+#endif
+          int i0 = -1, i1 = -1, i2 = -1;
+          f4 y0[KIT], y1[KIT], y2[KIT];
+#pragma unroll
+          for (int k = 0; k < KIT; ++k) y0[k] = y1[k] = y2[k] = f4{0.f, 0.f, 0.f, 0.f};
           auto body = [&](int j, f4(&xc)[KIT], f4(&xnext)[KIT]) {
             const int el = e0 + j;
-            const uint4 R2 = rec[e0 + min(j + 2, per - 1)];
-            // 1st: the loads this entry depends on (bank rows of a register set that changes vertex) ...
+            const uint4 R2 = rec[min(el + 2, cn - 1)];
+            // 1st: the loads this entry depends on (bank rows of a changed vertex slot) ...
             const int n0 = (int)(R0.y & 0xffffu), n1 = (int)(R0.y >> 16), n2 = (int)R0.z;
             if (n0 != i0) {
               i0 = n0;
               const gf4p B = (gf4p)(bbytes + ((uint32_t)n0 * (uint32_t)(D * 4) + gl16));
 #pragma unroll
-              for (int k = 0; k < KIT; ++k) y0[k] = (GRAD && (NEMO_ABL & 2)) ? f4{(float)n0, 1.f, 2.f, 3.f} : B[LPP * k];
+              for (int k = 0; k < KIT; ++k) y0[k] = (GRAD && (NEMO_ABL & 2)) ? f4{(float)n0, 1.f, 2.f, 3.f} : (GRAD && (NEMO_ABL & 16)) ? ((const f4 *)L.list)[((n0 & 31) * (D / 4) + gl + LPP * k) & 2047] : B[LPP * k];
             }
             if (n1 != i1) {
               i1 = n1;
               const gf4p B = (gf4p)(bbytes + ((uint32_t)n1 * (uint32_t)(D * 4) + gl16));
 #pragma unroll
-              for (int k = 0; k < KIT; ++k) y1[k] = (GRAD && (NEMO_ABL & 2)) ? f4{(float)n1, 1.f, 2.f, 3.f} : B[LPP * k];
+              for (int k = 0; k < KIT; ++k) y1[k] = (GRAD && (NEMO_ABL & 2)) ? f4{(float)n1, 1.f, 2.f, 3.f} : (GRAD && (NEMO_ABL & 16)) ? ((const f4 *)L.list)[((n1 & 31) * (D / 4) + gl + LPP * k) & 2047] : B[LPP * k];
             }
             if (n2 != i2) {
               i2 = n2;
               const gf4p B = (gf4p)(bbytes + ((uint32_t)n2 * (uint32_t)(D * 4) + gl16));
 #pragma unroll
-              for (int k = 0; k < KIT; ++k) y2[k] = (GRAD && (NEMO_ABL & 2)) ? f4{(float)n2, 1.f, 2.f, 3.f} : B[LPP * k];
+              for (int k = 0; k < KIT; ++k) y2[k] = (GRAD && (NEMO_ABL & 2)) ? f4{(float)n2, 1.f, 2.f, 3.f} : (GRAD && (NEMO_ABL & 16)) ? ((const f4 *)L.list)[((n2 & 31) * (D / 4) + gl + LPP * k) & 2047] : B[LPP * k];
             }
             // ... 2nd: the next entry's feature row, which stays in flight (vmcnt is in order)
             {
@@ -699,17 +768,16 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
             }
             float s0 = (A0.x + A0.y) + (A0.z + A0.w), s1 = (A1.x + A1.y) + (A1.z + A1.w),
                   s2 = (A2.x + A2.y) + (A2.z + A2.w);
-            const bool valid = (R0.w & 0x100u) != 0;
             if (LPP >= 16) {
               if (LPP >= 32) {
                 s0 += __shfl_xor(s0, 16); s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
               }
               const float w = sum3_row16(s0, s1, s2);  // quad q of the row holds the total of value q (q < 3)
               // value q belongs to vertex slot (code >> 2q) & 3: phase B reads the hand-off buffer in slot order
-              if (valid && (gl & 3) == 0 && gl < 12) gbuf[3 * el + ((R0.w >> ((gl >> 2) * 2)) & 3u)] = w;
+              if (el < cn && (gl & 3) == 0 && gl < 12) gbuf[3 * el + ((R0.w >> ((gl >> 2) * 2)) & 3u)] = w;
             } else {
               const float g0 = sum8(s0), g1 = sum8(s1), g2 = sum8(s2);
-              if (gl == 0 && valid) {
+              if (gl == 0 && el < cn) {
                 gbuf[3 * el + (R0.w & 3u)] = g0; gbuf[3 * el + ((R0.w >> 2) & 3u)] = g1; gbuf[3 * el + ((R0.w >> 4) & 3u)] = g2;
               }
             }
@@ -727,10 +795,15 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
           }
         }
         STAMP(8);
-        // ---------------- phase B: this lane's entries -> its 13 contributions
+        // ---------------- phase B: this lane's pixels -> its 13 contributions
+#if !NEMO_SEG
+        float pl = 0.f;
+        float GR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float GT[3] = {0.f, 0.f, 0.f};
+#endif
 #pragma unroll
         for (int u = 0; u < CH / 64; ++u)
-        if (vld[u]) {
+        if (u * 64 + lane < cn) {
           const uint32_t ent_b = ent_bs[u];
           const float cl = cls[u];
           const int lb = u * 64 + lane;
@@ -811,22 +884,34 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
             }
           }
         }
+#if NEMO_SEG
         STAMP(9);
+        cb = cb_next;
       }
-      {
-        float pv[13];
-        pv[0] = wave_sum_dpp(pl);
-        if (GRAD) {
+      const int pslot = wave;  // the wave's partials (fixed DPP tree), written by one lane
+#else
+        const int pslot = ccur;  // chunk partials (fixed DPP tree), written by one lane
+#endif
+        {
+          float pv[13];
+          pv[0] = wave_sum_dpp(pl);
+          if (GRAD) {
 #pragma unroll
-          for (int i = 0; i < 9; ++i) pv[1 + i] = wave_sum_dpp(GR[i]);
+            for (int i = 0; i < 9; ++i) pv[1 + i] = wave_sum_dpp(GR[i]);
 #pragma unroll
-          for (int i = 0; i < 3; ++i) pv[10 + i] = wave_sum_dpp(GT[i]);
+            for (int i = 0; i < 3; ++i) pv[10 + i] = wave_sum_dpp(GT[i]);
+          }
+          if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) part[pslot * 16 + i] = pv[i];
+          }
         }
-        if (lane == 0) {
-#pragma unroll
-          for (int i = 0; i < NP; ++i) part[wave * 16 + i] = pv[i];
-        }
+#if !NEMO_SEG
+        STAMP(9);
+        ccur = cnxt;
+        cnxt = grab();
       }
+#endif
     }
     STAMP(4);
 #ifdef NEMO_STAMPS
@@ -845,11 +930,12 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       constexpr int NPB = GRAD ? 13 : 1;
       if (wave == 0 && lane < NPB) {
         const float *part = (const float *)L.zb;
-        const int nchunks = NW;
+        const int nchunks = NEMO_SEG ? NW : plan_chunks(ntot).nchunks;
         float t = L.ust[U_TOT + lane];
         for (int c = 0; c < nchunks; ++c) t += part[c * 16 + lane];
         L.ust[U_TOT + lane] = t;
       }
+      if (tid == 0) *(int *)(L.ust + U_CTR) = 0;
     }
     __syncthreads();  // band's z-buffer / lists are reused by the next band
     STAMP(5);
@@ -1154,7 +1240,7 @@ __global__ void campos_kernel(const float *C, const float *theta, const float *e
 }
 
 template <bool PERSP, bool BIG>
-__global__ __launch_bounds__(NT, NEMO_WPE) void raster_kernel(KParams P, const MeshDesc *meshes, const int32_t *mesh_idx,
+__global__ __launch_bounds__(NT, 4) void raster_kernel(KParams P, const MeshDesc *meshes, const int32_t *mesh_idx,
                                                        const float *Rs, const float *Ts, int32_t *p2f, float *bary,
                                                        float *zbuf) {
   const int n = blockIdx.x;
@@ -1175,7 +1261,7 @@ __global__ __launch_bounds__(NT, NEMO_WPE) void raster_kernel(KParams P, const M
 
 // One evaluation per job at given poses (teacher-forced parity entry point).
 template <int D, bool PERSP, bool BIG>
-__global__ __launch_bounds__(NT, NEMO_WPE) void score_kernel(KParams P, const MeshDesc *meshes, const int32_t *img_idx,
+__global__ __launch_bounds__(NT, 4) void score_kernel(KParams P, const MeshDesc *meshes, const int32_t *img_idx,
                                                       const int32_t *mesh_idx, const float *feat, const float *clu,
                                                       const float *Cs, const float *thetas, float *loss, float *grad,
                                                       int32_t *ncov_out, u64 *counter) {
@@ -1216,7 +1302,7 @@ __global__ __launch_bounds__(NT, NEMO_WPE) void score_kernel(KParams P, const Me
 // depends on the mesh and the pose only, so its face-major list is built once per (mesh, grid, pose)
 // and every image's grid search consumes it.  One workgroup per (pair, pose).
 template <bool PERSP, bool BIG>
-__global__ __launch_bounds__(NT, NEMO_WPE) void prerender_kernel(KParams P, const MeshDesc *meshes, const int32_t *pair_mesh,
+__global__ __launch_bounds__(NT, 4) void prerender_kernel(KParams P, const MeshDesc *meshes, const int32_t *pair_mesh,
                                                           const int32_t *pair_grid, const float *gridC,
                                                           const float *gridTheta, int G, uint32_t *list, int32_t *cnt,
                                                           size_t stride) {
@@ -1243,7 +1329,7 @@ __global__ __launch_bounds__(NT, NEMO_WPE) void prerender_kernel(KParams P, cons
 // and b+8 share an XCD under round-robin dispatch; L2 affinity only, never
 // correctness): the image's feature rows are then served from that XCD's L2.
 template <int D, bool PERSP, bool BIG>
-__global__ __launch_bounds__(NT, NEMO_WPE) void grid_kernel(KParams P, const MeshDesc *meshes, int N, const int32_t *img_idx,
+__global__ __launch_bounds__(NT, 4) void grid_kernel(KParams P, const MeshDesc *meshes, int N, const int32_t *img_idx,
                                                      const int32_t *mesh_idx, const int32_t *grid_idx,
                                                      const float *feat, const float *clu, const float *gridC,
                                                      const float *gridTheta, int G, float *losses, u64 *counter,
@@ -1700,7 +1786,7 @@ __global__ void grid_argmin_kernel(int N, int G, const float *losses, const int3
 // initial pose (one rasterisation per job, 1/steps of the solve's work) and solve_order_kernel sorts the job
 // ids by that count, descending (counting sort, 64-pixel buckets); workgroup b of the solve runs job order[b].
 template <bool PERSP, bool BIG>
-__global__ __launch_bounds__(NT, NEMO_WPE) void solve_cost_kernel(KParams P, const MeshDesc *meshes, const int32_t *mesh_idx,
+__global__ __launch_bounds__(NT, 4) void solve_cost_kernel(KParams P, const MeshDesc *meshes, const int32_t *mesh_idx,
                                                            const float *C0, const float *theta0, const float *trans0,
                                                            int32_t *cost) {
   const int n = blockIdx.x;
@@ -1743,7 +1829,7 @@ __global__ __launch_bounds__(1024) void solve_order_kernel(int N, const int32_t 
 // runs the serial part of every step (camera, camera backward, Adam) and hands
 // R, T to the workgroup through LDS; (C, theta) and the Adam moments live in LDS.
 template <int D, bool PERSP, bool BIG>
-__global__ __launch_bounds__(NT, NEMO_WPE) void solve_kernel(KParams P, const MeshDesc *meshes, const int32_t *img_idx,
+__global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc *meshes, const int32_t *img_idx,
                                                       const int32_t *mesh_idx, const float *feat, const float *clu,
                                                       const float *C0, const float *theta0, const float *trans0,
                                                       int ndof, const float *adam_tab, int steps, float beta1,
@@ -1854,7 +1940,7 @@ __global__ __launch_bounds__(NT, NEMO_WPE) void solve_kernel(KParams P, const Me
 // grad_out plays the role of the feature map, and the block totals dL/dR, dL/dT
 // are written out for torch autograd to chain into campos / theta.
 template <int D, bool PERSP, bool BIG>
-__global__ __launch_bounds__(NT, NEMO_WPE) void interp_bwd_kernel(KParams P, const MeshDesc *meshes, const int32_t *mesh_idx,
+__global__ __launch_bounds__(NT, 4) void interp_bwd_kernel(KParams P, const MeshDesc *meshes, const int32_t *mesh_idx,
                                                            const float *Rs, const float *Ts, const float *grad_out,
                                                            float *grad_R, float *grad_T) {
   const int n = blockIdx.x;
@@ -1997,11 +2083,11 @@ static int plan_lds(nemo_ctx *ctx) {
   if (hw > 65536)
     return fail(ctx, NEMO_ERR_UNSUPPORTED, "window %dx%d has more than 65536 pixels (16-bit pixel ids)", c.win_h, c.win_w);
   const long misc = (NW * RED_N + UST_N + c.raster_size + 12) * 4 + 128;
-  const long fixed = (long)(NW * CH * (12 + 16) + PART_FLOATS * 4 + 192);  // score-phase scratch hosted by the z-buffer region
+  const long fixed = (long)(NW * CH * (12 + 16) + 64 * (2 * NW + 24) + 192);  // score-phase scratch hosted by the z-buffer region
   auto cap_for = [&](long avail) {
     long cap = avail / (8 + 4);
     if (cap > hw) cap = hw;
-    if (avail - fixed < cap * 4) cap = (avail - fixed) / 4;
+    if (avail - fixed < cap * 4 + 64 * (cap / CH)) cap = (avail - fixed) / 5;
     return cap;
   };
   long cap = cap_for((long)LDS_BUDGET - (long)vmax * 16 - (long)fmax * FACE_BYTES - misc);
