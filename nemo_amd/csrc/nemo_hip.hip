@@ -1999,6 +1999,44 @@ __global__ __launch_bounds__(256) void clutter_kernel(const float *__restrict__ 
   if (half == 0 && pix0 + i < npix) out[pix0 + i] = best;
 }
 
+// Clutter score for a small bank (K <= 8; the reference's mean clutter vector is K = 1, code/MeshPoseSolveAll.py:207):
+// a matrix-core tile would be all padding, and the pass is a pure stream of the feature maps.  D/8 lanes per pixel
+// read the pixel's row as two coalesced 16-byte loads per lane (all rows of a wave's 8 iterations in flight at once),
+// the clutter vectors come from L1, and a DPP tree reduces each dot product.
+template <int D>
+__global__ __launch_bounds__(256) void clutter_dot_kernel(const float *__restrict__ feat, size_t npix,
+                                                          const float *__restrict__ cbank, int K,
+                                                          float *__restrict__ out) {
+  constexpr int LPP = D / 8, GPW = 64 / LPP, IT = 8;
+  const int lane = threadIdx.x & 63, gl = lane & (LPP - 1), grp = lane / LPP;
+  const size_t p0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (GPW * IT) + grp;
+  f4 x0[IT], x1[IT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const size_t p = p0 + (size_t)it * GPW;
+    const f4 *xp = (const f4 *)(feat + (p < npix ? p : npix - 1) * D) + gl;
+    x0[it] = __builtin_nontemporal_load(xp);
+    x1[it] = __builtin_nontemporal_load(xp + LPP);
+  }
+  float best[IT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) best[it] = -INFINITY;
+  for (int k = 0; k < K; ++k) {
+    const f4 *cp = (const f4 *)(cbank + (size_t)k * D) + gl;
+    const f4 c0 = cp[0], c1 = cp[LPP];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const f4 a = __builtin_elementwise_fma(x1[it], c1, x0[it] * c0);
+      best[it] = fmaxf(best[it], sum_group<LPP>((a.x + a.y) + (a.z + a.w)));
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const size_t p = p0 + (size_t)it * GPW;
+    if (gl == 0 && p < npix) out[p] = best[it];
+  }
+}
+
 // interpolate_face_attributes (lib/MeshUtils.py:129): 32 lanes per pixel, 16 B each.
 __global__ void interpolate_kernel(int D, size_t npix_total, size_t hw, const MeshDesc *meshes,
                                    const int32_t *mesh_idx, const int32_t *p2f, const float *bary, float *out) {
@@ -2602,6 +2640,18 @@ int nemo_clutter_score(nemo_ctx *ctx, const float *d_feat, int32_t n_img, const 
   const size_t npix = (size_t)n_img * ctx->P.h * ctx->P.w;
   const size_t blocks = (npix + 127) / 128;
   if (blocks > 0x7fffffffULL) return fail(ctx, NEMO_ERR_UNSUPPORTED, "nemo_clutter_score: too many pixels for one launch");
+  if (K <= 8) {  // small bank: streaming dot products, no matrix-core tile
+    if (ctx->cfg.feat_dim == 128) {
+      const size_t nb = (npix + 4 * 32 - 1) / (4 * 32);  // 4 waves x (4 pixels x 8 iterations)
+      hipLaunchKernelGGL((clutter_dot_kernel<128>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, d_feat, npix, d_cbank, K, d_out);
+    } else {
+      const size_t nb = (npix + 4 * 16 - 1) / (4 * 16);  // 4 waves x (2 pixels x 8 iterations)
+      if (nb > 0x7fffffffULL) return fail(ctx, NEMO_ERR_UNSUPPORTED, "nemo_clutter_score: too many pixels for one launch");
+      hipLaunchKernelGGL((clutter_dot_kernel<256>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, d_feat, npix, d_cbank, K, d_out);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return NEMO_OK;
+  }
   if (ctx->cfg.feat_dim == 128)
     hipLaunchKernelGGL((clutter_kernel<128>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_feat, npix, d_cbank, K, d_out);
   else
