@@ -156,7 +156,9 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
  * Scheduling (results do not depend on it): for N > 64 the jobs are started longest first -- one
  * rasterisation per job counts the pixels covered at (C0, theta0), a device counting sort orders the job
  * ids, workgroup b runs job order[b]; the int32[2N] workspace is kept by the context and grown on demand.
- * NEMO_SOLVE_ORDER=0 in the environment launches in index order. */
+ * Inside windows of 64 ranks of that order the jobs are dealt to the XCDs (workgroup b runs on XCD b % 8) by mesh,
+ * so that an XCD's L2 keeps few vertex banks.  NEMO_SOLVE_ORDER=0 in the environment launches in index order,
+ * NEMO_SOLVE_AFFINITY=0 skips the XCD pass. */
 int nemo_solve(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t *d_mesh_idx,
                const float *d_feat, const float *d_clu, const float *d_C0, const float *d_theta0,
                float *d_pose, float *d_loss, float *d_trace, void *stream);

@@ -1825,6 +1825,36 @@ __global__ __launch_bounds__(1024) void solve_order_kernel(int N, const int32_t 
   for (int n = threadIdx.x; n < N; n += blockDim.x) order[atomicAdd(&cnt[bucket(cost[n])], 1)] = n;
 }
 
+// XCD affinity of the launch order.  Workgroup b is dispatched to XCD b % 8, and each XCD has its own 4 MiB L2; with
+// a dozen meshes in a batch their vertex banks (0.56 MB each) do not all stay resident in one L2.  Inside every
+// window of 64 consecutive ranks of the cost-sorted order (8 slots per XCD; costs within a window are alike, so the
+// longest-first property is kept) the jobs are dealt so that a mesh lands on its preferred XCD
+// (mesh * 8 / n_meshes) while that XCD has slots left in the window, on the nearest XCD with a free slot otherwise.
+// One thread per window.  Scheduling only.
+__global__ void solve_affinity_kernel(int N, int n_meshes, const int32_t *mesh_idx, int32_t *order) {
+  const int base = (int)(blockIdx.x * blockDim.x + threadIdx.x) * 64;
+  if (base >= N) return;
+  const int len = min(64, N - base);
+  int32_t in[64], out[64];
+  int used[8], cap[8];
+  for (int x = 0; x < 8; ++x) { used[x] = 0; cap[x] = (len - x + 7) / 8; }  // slots i < len with i % 8 == x
+  for (int i = 0; i < len; ++i) in[i] = order[base + i];
+  unsigned long long left = 0;
+  for (int i = 0; i < len; ++i) {
+    const int x = max(0, min(7, (int)(((long long)mesh_idx[in[i]] * 8) / max(n_meshes, 1))));
+    if (used[x] < cap[x]) out[x + 8 * used[x]++] = in[i]; else left |= 1ull << i;
+  }
+  for (int i = 0; i < len; ++i) {
+    if (!((left >> i) & 1ull)) continue;
+    const int x = max(0, min(7, (int)(((long long)mesh_idx[in[i]] * 8) / max(n_meshes, 1))));
+    for (int d = 1; d < 8; ++d) {
+      const int y = (x + ((d & 1) ? (d + 1) / 2 : 8 - d / 2)) & 7;  // x+1, x-1, x+2, x-2, ...
+      if (used[y] < cap[y]) { out[y + 8 * used[y]++] = in[i]; break; }
+    }
+  }
+  for (int i = 0; i < len; ++i) order[base + i] = out[i];
+}
+
 // The fused solve: code/MeshPoseSolveAll.py:227-250 in one launch.  Thread 0
 // runs the serial part of every step (camera, camera backward, Adam) and hands
 // R, T to the workgroup through LDS; (C, theta) and the Adam moments live in LDS.
@@ -2596,6 +2626,12 @@ static int launch_solve(nemo_ctx *ctx, const char *who, int32_t N, const int32_t
               ndof == 6 ? d_trans0 : (const float *)nullptr, d_cost);
     hipLaunchKernelGGL(solve_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (int)N, (const int32_t *)d_cost, d_ord);
     HIP_TRY(ctx, hipGetLastError());
+    const char *aff = getenv("NEMO_SOLVE_AFFINITY");
+    if (d_mesh_idx && ctx->n_meshes > 1 && !(aff && atoi(aff) == 0)) {
+      const int windows = (N + 63) / 64;
+      hipLaunchKernelGGL(solve_affinity_kernel, dim3((unsigned)((windows + 63) / 64)), dim3(64), 0, (hipStream_t)stream, (int)N,
+                         ctx->n_meshes, d_mesh_idx, d_ord);
+    }
     d_order = d_ord;
   }
   DISPATCH_DP(solve_kernel, dim3(N), ctx->P, ctx->d_meshes, d_img_idx, d_mesh_idx, d_feat, d_clu, d_C0, d_theta0, d_trans0,
