@@ -156,6 +156,28 @@ def test_rasterize_triangle_soup_fuzz(oracle, persp):
         assert (p2f >= 0).any()
 
 
+def test_crop_window_equals_slice_of_full_raster():
+    """center_crop_fun (lib/MeshUtils.py:148-150) is a row / column window inside the rasteriser: its output is,
+    bit for bit, the slice of the full S x S raster the reference would have cropped; barycentrics of covered
+    pixels sum to 1 and uncovered pixels carry the -1 fill."""
+    from nemo_amd.engine import PoseEngine
+    sc = make_scene('car', (256, 384), 300, n_img=1, seed=12)
+    S, h, w = sc.geo.S, sc.geo.h, sc.geo.w
+    win, full = _engine(sc), PoseEngine(S, (S, S), sc.D)
+    full.register_mesh(sc.verts, sc.faces, sc.bank)
+    rng = np.random.default_rng(8)
+    C, th = random_poses(rng, 8, sc.distance, spread=0.3)
+    R, T = win.campos_to_R_T(_dev(C), _dev(th))
+    pw, bw, zw = win.rasterize(R, T, want_zbuf=True)
+    pf, bf, zf = full.rasterize(R, T, want_zbuf=True)
+    r0, c0 = sc.geo.r0, sc.geo.c0
+    assert torch.equal(pw, pf[:, r0:r0 + h, c0:c0 + w])
+    assert torch.equal(bw, bf[:, r0:r0 + h, c0:c0 + w]) and torch.equal(zw, zf[:, r0:r0 + h, c0:c0 + w])
+    cov = pw >= 0
+    assert cov.any() and (bw[cov].sum(-1) - 1).abs().max().item() < 1e-4  # three separately rounded quotients e_k / (area + kEps)
+    assert (bw[~cov] == -1).all()
+
+
 def test_interpolate_bit_exact(oracle):
     sc = make_scene(n_img=1)
     eng = _engine(sc)
