@@ -259,6 +259,24 @@ def test_grid_search(oracle):
         assert np.array_equal(C0[i].cpu().numpy(), gC[bo]) and th0[i].item() == gth[bo]
 
 
+def test_grid_search_first_minimum_wins():
+    """torch.min semantics of get_init_pos_rendered (code/MeshPoseSolveAll.py:97): among equal losses the first
+    grid pose wins.  The grid is listed twice, so every loss appears twice, bit-identical -- on the fly, from
+    pre-rendered lists and through the matrix-core path alike -- and the argmin stays in the first copy."""
+    sc = make_scene(n_img=3, seed=31)
+    eng = _engine(sc)
+    gC, gth = syn.pose_grid(sc.distance, n_azim=6, n_elev=2, n_theta=2)
+    G = len(gth)
+    dC, dth = _dev(np.concatenate([gC, gC])[None]), _dev(np.concatenate([gth, gth])[None])
+    feats, clus = _dev(sc.feats), _dev(sc.clus)
+    for stage in ('on the fly', 'pre-rendered'):
+        if stage == 'pre-rendered':
+            eng.grid_prerender(dC, dth, [(0, 0)])
+        C0, th0, best, losses = eng.grid_search(feats, clus, dC, dth)
+        assert torch.equal(losses[:, :G], losses[:, G:]), stage
+        assert (best < G).all() and torch.equal(best.long(), losses.argmin(dim=1)), stage
+
+
 @pytest.mark.parametrize('persp', [False, True])
 @pytest.mark.parametrize('mfma', [True, False])
 def test_grid_search_prerendered(oracle, persp, mfma, monkeypatch):
