@@ -445,6 +445,32 @@ def test_empty_batch_and_errors():
         PoseEngine(32, (16, 32), feat_dim=96)
 
 
+def test_non_finite_job_is_flagged_not_fatal():
+    """A job whose start pose is not finite (the reference scores such solves as pi/2, code/MeshPoseSolveAll.py:262-263)
+    comes back non-finite with status 0 in the gathered record; the launch completes and the other jobs of the batch
+    are bit-identical to the same jobs solved without it."""
+    from nemo_amd.pose_solver import SolverConfig
+    from nemo_amd.workloads import twelve_class_workload
+    wl = twelve_class_workload(6, seed=21, cfg=SolverConfig(total_epochs=40))
+    s, eng = wl.solver, wl.solver.engine
+    clu = eng.clutter_score(wl.feats, wl.clutter)
+    C0, th0, _, _ = eng.grid_search(wl.feats, clu, s.grid_C, s.grid_theta, mesh_idx=wl.mesh_idx, grid_idx=wl.mesh_idx)
+    good_pose, good_loss = eng.solve(wl.feats, clu, C0, th0, mesh_idx=wl.mesh_idx)[:2]
+    bad_C, bad_th = C0.clone(), th0.clone()
+    bad_C[2, 1] = float('nan')
+    bad_th[4] = float('inf')
+    pose, loss = eng.solve(wl.feats, clu, bad_C, bad_th, mesh_idx=wl.mesh_idx)[:2]
+    torch.cuda.synchronize()
+    keep = torch.tensor([0, 1, 3, 5], device='cuda')
+    assert torch.equal(pose[keep], good_pose[keep]) and torch.equal(loss[keep], good_loss[keep])
+    assert not torch.isfinite(pose[2]).all() and not torch.isfinite(pose[4]).all()
+    from nemo_amd.pose_solver import SolveResult
+    from nemo_amd.mesh_utils import camera_position_to_spherical_angle
+    d, e, a = camera_position_to_spherical_angle(pose[:, :3])
+    rec = SolveResult(pose[:, 3], d, e, a, loss, pose[:, :3], torch.zeros(6, dtype=torch.int32, device='cuda')).packed().cpu().numpy()
+    assert rec[:, 6].tolist() == [1.0, 1.0, 0.0, 1.0, 0.0, 1.0]
+
+
 def test_against_committed_fixture():
     """HIP path vs tests/golden/path_small.npz (oracle outputs committed with their generator)."""
     import os
