@@ -443,6 +443,15 @@ def test_empty_batch_and_errors():
     with pytest.raises(_lib.NemoHipError):
         from nemo_amd.engine import PoseEngine
         PoseEngine(32, (16, 32), feat_dim=96)
+    # size limits are refused with a clear error, nothing aborts: 16-bit vertex / face ids, 16-bit window pixel ids
+    big_v = np.zeros((70000, 3), np.float32)
+    with pytest.raises(_lib.NemoHipError, match='16-bit'):
+        eng.register_mesh(big_v, np.zeros((10, 3), np.int32), np.zeros((70000, sc.D), np.float32))
+    with pytest.raises(_lib.NemoHipError, match='65536'):
+        PoseEngine(512, (300, 400), feat_dim=128)
+    # the engine is still usable after the refusals
+    loss, _, _ = eng.score_fwd_bwd(_dev(sc.feats), _dev(sc.clus), _dev(np.array([[0, 0, sc.distance]])), _dev(np.zeros(1)))
+    assert torch.isfinite(loss).all()
 
 
 def test_non_finite_job_is_flagged_not_fatal():
