@@ -9,7 +9,10 @@
  *  - `stream` is a hipStream_t passed as void* (NULL = default stream);
  *  - every call returns 0 on success or a negative code (NEMO_ERR_*, or
  *    -(1000 + hipError_t)); nemo_last_error() gives the text.  Nothing aborts;
- *  - no entry point below the "setup" group allocates or synchronises;
+ *  - no entry point below the "setup" group allocates, frees, synchronises or reads the environment: the
+ *    workspaces they need are sized by nemo_workspace_reserve (set-up group), and a hot call whose batch does
+ *    not fit the reservation returns NEMO_ERR_STATE instead of growing it.  The workspaces belong to the
+ *    context, so a context serves ONE stream at a time (use one context per concurrent stream);
  *  - meshes hold PRE-PROCESSED vertices (x,y,z)->(x,z,-y) as the reference's
  *    pre_process_mesh_pascal does (code/lib/MeshUtils.py:115-117);
  *  - feature maps are PIXEL-MAJOR f32 [n_img][h][w][D] (the reference's
@@ -72,6 +75,16 @@ int nemo_mesh_register(nemo_ctx *ctx, const float *d_verts, int32_t V, const int
  * prepared in double by the caller exactly like torch's Python side. */
 int nemo_set_schedule(nemo_ctx *ctx, const float *h_tab, int32_t steps, float beta1, float beta2,
                       float eps);
+
+/* Sizes every workspace of the hot entry points once (SURVEY 8b "no allocation in hot calls"; the reference
+ * allocates freely per call: every torch op at code/MeshPoseSolveAll.py:236-245 creates its outputs).
+ * max_jobs = largest N of any later call; max_grid_poses = largest G of nemo_grid_search (0: none).
+ * Covers: the solve's launch-order arrays (int32[2 max_jobs]), the grid search's job grouping and per-chunk
+ * partial sums (ceil(h w / 64) * max_jobs * max_grid_poses floats), and, for meshes whose tables do not fit the
+ * LDS, one table slice per workgroup (at most 2048).  Grows only; may be called again (between hot calls).
+ * Environment switches (NEMO_GRID_NO_MFMA, NEMO_SOLVE_ORDER, NEMO_SOLVE_AFFINITY, NEMO_SLOT_ORDER,
+ * NEMO_PRERENDER_MAP_GB ...) are read once, in nemo_ctx_create. */
+int nemo_workspace_reserve(nemo_ctx *ctx, int32_t max_jobs, int32_t max_grid_poses);
 
 /* ---- hot path (asynchronous on `stream`, no allocation) ------------------- */
 
@@ -155,10 +168,11 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
  * step, or NULL.
  * Scheduling (results do not depend on it): for N > 64 the jobs are started longest first -- one
  * rasterisation per job counts the pixels covered at (C0, theta0), a device counting sort orders the job
- * ids, workgroup b runs job order[b]; the int32[2N] workspace is kept by the context and grown on demand.
+ * ids, workgroup b runs job order[b]; the int32[2N] workspace comes from nemo_workspace_reserve
+ * (NEMO_ERR_STATE if N exceeds it).
  * Inside windows of 64 ranks of that order the jobs are dealt to the XCDs (workgroup b runs on XCD b % 8) by mesh,
- * so that an XCD's L2 keeps few vertex banks.  NEMO_SOLVE_ORDER=0 in the environment launches in index order,
- * NEMO_SOLVE_AFFINITY=0 skips the XCD pass. */
+ * so that an XCD's L2 keeps few vertex banks.  NEMO_SOLVE_ORDER=0 in the environment (at nemo_ctx_create) launches
+ * in index order, NEMO_SOLVE_AFFINITY=0 skips the XCD pass. */
 int nemo_solve(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t *d_mesh_idx,
                const float *d_feat, const float *d_clu, const float *d_C0, const float *d_theta0,
                float *d_pose, float *d_loss, float *d_trace, void *stream);

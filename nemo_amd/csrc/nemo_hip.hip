@@ -1333,22 +1333,29 @@ __global__ __launch_bounds__(NT, 4) void grid_kernel(KParams P, const MeshDesc *
                                                      const int32_t *mesh_idx, const int32_t *grid_idx,
                                                      const float *feat, const float *clu, const float *gridC,
                                                      const float *gridTheta, int G, float *losses, u64 *counter,
-                                                     PreStore pre, int skip_prepared, unsigned block_base) {
+                                                     PreStore pre, const int32_t *work, unsigned block_base,
+                                                     unsigned stride) {
+  // work == nullptr: every job, one (job, pose block) item per workgroup (stride 0; large meshes: launches are
+  // sliced by block_base and the scratch slice is blockIdx.x).  Otherwise work[0] jobs listed in work[1..] -- those
+  // the matrix-core path did not take -- walked by a fixed number of workgroups with a stride; when that list is
+  // empty the launch costs a few microseconds.
   const int GB = (G + GRID_POSES_PER_WG - 1) / GRID_POSES_PER_WG;
-  const unsigned bid = blockIdx.x + block_base;  // large meshes: launches are sliced, the scratch slice is blockIdx.x
+  const int nw = work ? work[0] : N;
+  const unsigned total = 8u * (unsigned)((nw + 7) / 8) * (unsigned)GB;
+  const Lds L = lds_carve(smem, P);
+  for (unsigned bid = blockIdx.x + block_base; bid < total; bid += stride) {
   const int xcd = bid & 7, k = bid >> 3;
-  const int n = (k / GB) * 8 + xcd, g0 = (k % GB) * GRID_POSES_PER_WG;
-  if (n >= N) return;
+  const int wn = (k / GB) * 8 + xcd, g0 = (k % GB) * GRID_POSES_PER_WG;
+  if (wn < nw) {
+  const int n = work ? work[1 + wn] : wn;
   const int mi = mesh_idx ? mesh_idx[n] : 0;
   const MeshDesc M = meshes[mi];
   const int img = img_idx ? img_idx[n] : n;
   const int gi = grid_idx ? grid_idx[n] : 0;
   const int slot = (pre.slot && gi < MAX_GRIDS) ? pre.slot[mi * MAX_GRIDS + gi] : -1;
-  if (skip_prepared && slot >= 0) return;  // handled by the MFMA path over the pre-rendered maps
   const size_t hw = (size_t)P.h * P.w;
   const float *f = feat + (size_t)img * hw * D;
   const float *c = clu ? clu + (size_t)img * hw : nullptr;
-  const Lds L = lds_carve(smem, P);
   load_world_verts<BIG>(P, L, M);
   loss_constant(P, L, c);
   u64 ncov_sum = 0;
@@ -1377,6 +1384,9 @@ __global__ __launch_bounds__(NT, 4) void grid_kernel(KParams P, const MeshDesc *
     }
   }
   if (threadIdx.x == 0 && counter) atomicAdd(counter, ncov_sum);
+  }
+  if (stride == 0) break;
+  }
 }
 
 typedef float f16v __attribute__((ext_vector_type(16)));
@@ -1408,9 +1418,11 @@ __global__ void gather_pose_kernel(int n, const int32_t *gidx, const float *grid
 // job_slot[n] the slot of job n (-1: not pre-rendered, evaluated on the fly by grid_kernel).
 __global__ __launch_bounds__(1024) void grid_group_kernel(int N, const int32_t *mesh_idx, const int32_t *grid_idx,
                                                           const int32_t *slot_tab, int n_pairs, int32_t *order,
-                                                          int32_t *slot_start, int32_t *job_slot) {
+                                                          int32_t *slot_start, int32_t *job_slot, int32_t *work) {
   __shared__ int cnt[GP_MAX_PAIRS + 1];
+  __shared__ int n_work;
   for (int i = threadIdx.x; i <= n_pairs; i += blockDim.x) cnt[i] = 0;
+  if (threadIdx.x == 0) n_work = 0;
   __syncthreads();
   for (int n = threadIdx.x; n < N; n += blockDim.x) {
     const int mi = mesh_idx ? mesh_idx[n] : 0, gi = grid_idx ? grid_idx[n] : 0;
@@ -1433,7 +1445,10 @@ __global__ __launch_bounds__(1024) void grid_group_kernel(int N, const int32_t *
   for (int n = threadIdx.x; n < N; n += blockDim.x) {
     const int sl = job_slot[n];
     if (sl >= 0) order[atomicAdd(&cnt[sl], 1)] = n;  // order inside a slot is irrelevant: jobs are independent
+    else work[1 + atomicAdd(&n_work, 1)] = n;        // left to grid_kernel (rendered on the fly / list path)
   }
+  __syncthreads();
+  if (threadIdx.x == 0) work[0] = n_work;
 }
 
 template <int D>
@@ -2112,6 +2127,7 @@ struct nemo_ctx {
   int pre_G, pre_pairs;
   // grid-search workspace (grown on demand): job grouping and per-chunk partial sums
   int32_t *d_gs_order, *d_gs_start, *d_gs_jobslot;
+  int32_t *d_gs_work;  // [0] = number of jobs without a pre-rendered pair, [1..] their ids (grid_kernel's work list)
   float *d_gs_partial;
   size_t gs_jobs_cap, gs_partial_cap;
   uint8_t *d_slot_order[MAX_MESHES];  // per mesh (MeshDesc::slot_order), owned by the context
@@ -2119,6 +2135,12 @@ struct nemo_ctx {
   size_t big_cap;
   int32_t *d_so;         // solve launch order workspace: cost[so_cap], order[so_cap]
   size_t so_cap;
+  size_t big_blocks_req; // workgroups the BIG scratch was reserved for (re-applied when a mesh registration changes the slice size)
+  int device;            // HIP device the context was created on
+  int n_cu;              // its compute-unit count (cached: hipGetDeviceProperties is slow)
+  // environment switches, read ONCE in nemo_ctx_create (hot calls never call getenv)
+  int env_grid_no_mfma, env_grid_mfma_direct, env_solve_stagger, env_solve_order, env_solve_affinity, env_slot_identity;
+  double env_prerender_map_gb;
   char err[512];
 };
 
@@ -2181,10 +2203,13 @@ static int plan_lds(nemo_ctx *ctx) {
 
 // BIG meshes: one scratch slice (screen vertices, face ids, per-face fragment boxes) per workgroup of a launch.
 constexpr unsigned BIG_MAX_BLOCKS = 2048;  // launches with more workgroups are issued in slices of this many
-static int ensure_big_scratch(nemo_ctx *ctx, size_t nblocks) {
-  if (!ctx->P.big) return NEMO_OK;
+// Set-up side: (re)allocates the scratch for `nblocks` workgroups (nemo_workspace_reserve, nemo_mesh_register,
+// nemo_grid_prerender -- all allowed to allocate and synchronise).
+static int reserve_big_scratch(nemo_ctx *ctx, size_t nblocks) {
   if (nblocks > BIG_MAX_BLOCKS) nblocks = BIG_MAX_BLOCKS;
-  const size_t need = nblocks * (size_t)ctx->P.big_stride;
+  if (nblocks > ctx->big_blocks_req) ctx->big_blocks_req = nblocks;
+  if (!ctx->P.big) return NEMO_OK;
+  const size_t need = ctx->big_blocks_req * (size_t)ctx->P.big_stride;
   if (need > ctx->big_cap) {
     hipFree(ctx->d_big);
     ctx->d_big = nullptr;
@@ -2192,6 +2217,18 @@ static int ensure_big_scratch(nemo_ctx *ctx, size_t nblocks) {
     HIP_TRY(ctx, hipMalloc(&ctx->d_big, need));
     ctx->big_cap = need;
   }
+  ctx->P.big_scratch = (unsigned long long)(uintptr_t)ctx->d_big;
+  return NEMO_OK;
+}
+// Hot side: never allocates; a launch that needs more slices than were reserved is refused.
+static int ensure_big_scratch(nemo_ctx *ctx, size_t nblocks) {
+  if (!ctx->P.big) return NEMO_OK;
+  if (nblocks > BIG_MAX_BLOCKS) nblocks = BIG_MAX_BLOCKS;
+  const size_t need = nblocks * (size_t)ctx->P.big_stride;
+  if (need > ctx->big_cap)
+    return fail(ctx, NEMO_ERR_STATE,
+                "large-mesh scratch holds %zu workgroup slices, this call needs %zu: call nemo_workspace_reserve first",
+                ctx->P.big_stride ? ctx->big_cap / ctx->P.big_stride : 0, nblocks);
   ctx->P.big_scratch = (unsigned long long)(uintptr_t)ctx->d_big;
   return NEMO_OK;
 }
@@ -2287,8 +2324,70 @@ int nemo_ctx_create(const nemo_config *cfg, nemo_ctx **out) {
   SET_LDS_B(interp_bwd_kernel, 256, false); SET_LDS_B(interp_bwd_kernel, 256, true);
 #undef SET_LDS_B
 #undef SET_LDS
+  hipFuncSetAttribute((const void *)feature_head_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  hipFuncSetAttribute((const void *)feature_head_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  // device facts and environment switches are read here, once; hot calls never query either
+  ctx->n_cu = 256;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&ctx->device) != hipSuccess) ctx->device = 0;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+  }
+  auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
+  ctx->env_grid_no_mfma = env_int("NEMO_GRID_NO_MFMA", 0);
+  ctx->env_grid_mfma_direct = env_int("NEMO_GRID_MFMA_DIRECT", 0);
+  ctx->env_solve_stagger = env_int("NEMO_SOLVE_STAGGER", 0);
+  ctx->env_solve_order = env_int("NEMO_SOLVE_ORDER", 1);
+  ctx->env_solve_affinity = env_int("NEMO_SOLVE_AFFINITY", 1);
+  ctx->env_slot_identity = env_int("NEMO_SLOT_ORDER", 1) == 0;
+  {
+    const char *v = getenv("NEMO_PRERENDER_MAP_GB");
+    ctx->env_prerender_map_gb = v ? atof(v) : 48.0;
+  }
   *out = ctx;
   return NEMO_OK;
+}
+
+/* Set-up call: sizes every workspace the hot entry points use, so that none of them allocates, frees or
+ * synchronises.  max_jobs = the largest N of any later call, max_grid_poses = the largest G of nemo_grid_search
+ * (0: no grid search).  Growing only; may be called again.  Workspaces belong to the context, so a context
+ * serves ONE stream at a time. */
+int nemo_workspace_reserve(nemo_ctx *ctx, int32_t max_jobs, int32_t max_grid_poses) {
+  if (!ctx || max_jobs < 0 || max_grid_poses < 0) return fail(ctx, NEMO_ERR_ARG, "nemo_workspace_reserve: bad argument");
+  const size_t N = (size_t)max_jobs, G = (size_t)max_grid_poses;
+  if (N > ctx->so_cap) {  // solve launch order: cost[N], order[N]
+    hipFree(ctx->d_so);
+    ctx->d_so = nullptr;
+    ctx->so_cap = 0;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_so, sizeof(int32_t) * 2 * N));
+    ctx->so_cap = N;
+  }
+  if (N > ctx->gs_jobs_cap) {  // grid search: job grouping by pre-render slot
+    hipFree(ctx->d_gs_order); hipFree(ctx->d_gs_jobslot); hipFree(ctx->d_gs_start); hipFree(ctx->d_gs_work);
+    ctx->d_gs_order = ctx->d_gs_jobslot = ctx->d_gs_start = ctx->d_gs_work = nullptr;
+    ctx->gs_jobs_cap = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_gs_order, sizeof(int32_t) * N));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_gs_jobslot, sizeof(int32_t) * N));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_gs_start, sizeof(int32_t) * (GP_MAX_PAIRS + 1)));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_gs_work, sizeof(int32_t) * (N + 1)));
+    ctx->gs_jobs_cap = N;
+  }
+  const size_t n_chunks = ((size_t)ctx->cfg.win_h * ctx->cfg.win_w + GP_PIX - 1) / GP_PIX;
+  const size_t need_partial = n_chunks * N * G;
+  if (need_partial > ctx->gs_partial_cap) {  // matrix-core grid search: per-chunk partial sums
+    hipFree(ctx->d_gs_partial);
+    ctx->d_gs_partial = nullptr;
+    ctx->gs_partial_cap = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_gs_partial, sizeof(float) * need_partial));
+    ctx->gs_partial_cap = need_partial;
+  }
+  // large meshes: one table slice per workgroup of the widest launch (per-job kernels: N; grid search: sliced)
+  size_t blocks = N;
+  if (G > 0) {
+    const size_t gb = 8 * ((N + 7) / 8) * ((G + GRID_POSES_PER_WG - 1) / GRID_POSES_PER_WG);
+    if (gb > blocks) blocks = gb;
+  }
+  return reserve_big_scratch(ctx, blocks);
 }
 
 int nemo_ctx_destroy(nemo_ctx *ctx) {
@@ -2298,7 +2397,7 @@ int nemo_ctx_destroy(nemo_ctx *ctx) {
   hipFree(ctx->d_adam);
   hipFree(ctx->d_pre_slot); hipFree(ctx->d_pre_cnt); hipFree(ctx->d_pre_pairs); hipFree(ctx->d_pre_list);
   hipFree(ctx->d_pre_maps); hipFree(ctx->d_gs_order); hipFree(ctx->d_gs_start); hipFree(ctx->d_gs_jobslot);
-  hipFree(ctx->d_gs_partial); hipFree(ctx->d_big); hipFree(ctx->d_so);
+  hipFree(ctx->d_gs_partial); hipFree(ctx->d_gs_work); hipFree(ctx->d_big); hipFree(ctx->d_so);
   for (int i = 0; i < ctx->n_meshes; ++i) hipFree(ctx->d_slot_order[i]);
   delete ctx;
   return NEMO_OK;
@@ -2323,12 +2422,17 @@ int nemo_mesh_register(nemo_ctx *ctx, const float *d_verts, int32_t V, const int
   // previous face untouched.  Results do not depend on it (the dot products are stored back by vertex slot).
   std::vector<int32_t> hf((size_t)3 * F);
   HIP_TRY(ctx, hipMemcpy(hf.data(), d_faces, sizeof(int32_t) * 3 * (size_t)F, hipMemcpyDeviceToHost));
+  for (size_t k = 0; k < hf.size(); ++k)
+    if (hf[k] < 0 || hf[k] >= V) {
+      ctx->vmax_seen = old_vmax; ctx->fmax_seen = old_fmax; plan_lds(ctx);
+      return fail(ctx, NEMO_ERR_ARG, "nemo_mesh_register: face %zu refers to vertex %d (V = %d)", k / 3, hf[k], V);
+    }
+  if ((rc = reserve_big_scratch(ctx, 0)) != NEMO_OK) return rc;  // the slice size may have grown: re-apply the reservation
   std::vector<uint8_t> order((size_t)F);
   {
     static const int perms[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
     int32_t prev[3] = {-1, -1, -1};
-    const char *so_env = getenv("NEMO_SLOT_ORDER");
-    const bool identity = so_env && atoi(so_env) == 0;  // experiments / invariance test: every face keeps its own order
+    const bool identity = ctx->env_slot_identity != 0;  // NEMO_SLOT_ORDER=0 (invariance test): every face keeps its own order
     for (int f = 0; f < F; ++f) {
       const int32_t *t = &hf[(size_t)3 * f];
       int best = -1, bp = 0;
@@ -2437,34 +2541,22 @@ int nemo_grid_search(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const i
   PreStore pre{nullptr, nullptr, nullptr, 0};
   const bool store_ok = ctx->pre_pairs > 0 && ctx->pre_G == G && ctx->pre_gridC == d_grid_C && ctx->pre_gridT == d_grid_theta;
   if (store_ok) pre = PreStore{ctx->d_pre_slot, ctx->d_pre_cnt, ctx->d_pre_list, (size_t)ctx->cfg.win_h * ctx->cfg.win_w};
-  const char *no_mfma = getenv("NEMO_GRID_NO_MFMA");
-  const bool mfma = store_ok && ctx->d_pre_maps && !(no_mfma && atoi(no_mfma));
+  const bool mfma = store_ok && ctx->d_pre_maps && !ctx->env_grid_no_mfma;
+  const int32_t *d_work = nullptr;
   if (mfma) {
     // matrix-core path over the dense pre-rendered maps; jobs without a stored pair fall through to grid_kernel
     const int hw = ctx->cfg.win_h * ctx->cfg.win_w, n_chunks = (hw + GP_PIX - 1) / GP_PIX;
     const size_t need_partial = (size_t)n_chunks * N * G;
-    if ((size_t)N > ctx->gs_jobs_cap) {
-      hipFree(ctx->d_gs_order); hipFree(ctx->d_gs_jobslot); hipFree(ctx->d_gs_start);
-      ctx->d_gs_order = ctx->d_gs_jobslot = ctx->d_gs_start = nullptr;
-      ctx->gs_jobs_cap = 0;
-      HIP_TRY(ctx, hipMalloc(&ctx->d_gs_order, sizeof(int32_t) * N));
-      HIP_TRY(ctx, hipMalloc(&ctx->d_gs_jobslot, sizeof(int32_t) * N));
-      HIP_TRY(ctx, hipMalloc(&ctx->d_gs_start, sizeof(int32_t) * (GP_MAX_PAIRS + 1)));
-      ctx->gs_jobs_cap = (size_t)N;
-    }
-    if (need_partial > ctx->gs_partial_cap) {
-      hipFree(ctx->d_gs_partial);
-      ctx->d_gs_partial = nullptr;
-      ctx->gs_partial_cap = 0;
-      HIP_TRY(ctx, hipMalloc(&ctx->d_gs_partial, sizeof(float) * need_partial));
-      ctx->gs_partial_cap = need_partial;
-    }
+    if ((size_t)N > ctx->gs_jobs_cap || need_partial > ctx->gs_partial_cap)
+      return fail(ctx, NEMO_ERR_STATE, "nemo_grid_search: workspace reserved for %zu jobs / %zu partial sums, this call needs "
+                  "%d / %zu: call nemo_workspace_reserve(ctx, >= %d, >= %d) first", ctx->gs_jobs_cap, ctx->gs_partial_cap, N,
+                  need_partial, N, G);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(grid_group_kernel, dim3(1), dim3(1024), 0, st, N, d_mesh_idx, d_grid_idx, ctx->d_pre_slot,
-                       ctx->pre_pairs, ctx->d_gs_order, ctx->d_gs_start, ctx->d_gs_jobslot);
+                       ctx->pre_pairs, ctx->d_gs_order, ctx->d_gs_start, ctx->d_gs_jobslot, ctx->d_gs_work);
+    d_work = ctx->d_gs_work;
     const int con = (ctx->cfg.clutter && d_clu) ? 1 : 0;
-    const char *old_k = getenv("NEMO_GRID_MFMA_DIRECT");
-    if (old_k && atoi(old_k)) {  // earlier variant: operands gathered straight from global memory by every wave
+    if (ctx->env_grid_mfma_direct) {  // earlier variant: operands gathered straight from global memory by every wave
       const int gy = (G + 511) / 512;  // poses beyond 512 go to further workgroups (grid.y)
       const dim3 grd((unsigned)(ctx->pre_pairs * n_chunks), (unsigned)gy), blk((unsigned)(64 * (((G < 512 ? G : 512) + 31) / 32)));
       if (ctx->cfg.feat_dim == 128)
@@ -2490,17 +2582,28 @@ int nemo_grid_search(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const i
                        ctx->d_gs_jobslot, d_clu, ctx->d_gs_partial, ctx->d_pre_cnt, d_losses, ctx->d_counter, con);
     HIP_TRY(ctx, hipGetLastError());
   }
-  if (ctx->P.big) {
+  if (d_work) {
+    // only the jobs the matrix-core path left over (device-side list): a fixed, small grid with a stride loop
+    const unsigned nb = (unsigned)(blocks < 2048 ? blocks : 2048);  // a multiple of 8 either way
+    int rc_ = ensure_big_scratch(ctx, nb);
+    if (rc_ != NEMO_OK) return rc_;
+    if (ctx->P.big)
+      DISPATCH_DPB(grid_kernel, true, dim3(nb), ctx->P, ctx->d_meshes, N, d_img_idx, d_mesh_idx, d_grid_idx, d_feat, d_clu,
+                   d_grid_C, d_grid_theta, G, d_losses, ctx->d_counter, pre, d_work, 0u, nb);
+    else
+      DISPATCH_DPB(grid_kernel, false, dim3(nb), ctx->P, ctx->d_meshes, N, d_img_idx, d_mesh_idx, d_grid_idx, d_feat, d_clu,
+                   d_grid_C, d_grid_theta, G, d_losses, ctx->d_counter, pre, d_work, 0u, nb);
+  } else if (ctx->P.big) {
     int rc_ = ensure_big_scratch(ctx, (size_t)blocks);
     if (rc_ != NEMO_OK) return rc_;
     for (long long b0 = 0; b0 < blocks; b0 += BIG_MAX_BLOCKS) {
       const unsigned nb = (unsigned)(blocks - b0 < (long long)BIG_MAX_BLOCKS ? blocks - b0 : (long long)BIG_MAX_BLOCKS);
       DISPATCH_DPB(grid_kernel, true, dim3(nb), ctx->P, ctx->d_meshes, N, d_img_idx, d_mesh_idx, d_grid_idx, d_feat, d_clu,
-                   d_grid_C, d_grid_theta, G, d_losses, ctx->d_counter, pre, mfma ? 1 : 0, (unsigned)b0);
+                   d_grid_C, d_grid_theta, G, d_losses, ctx->d_counter, pre, (const int32_t *)nullptr, (unsigned)b0, 0u);
     }
   } else {
     DISPATCH_DPB(grid_kernel, false, dim3((unsigned)blocks), ctx->P, ctx->d_meshes, N, d_img_idx, d_mesh_idx, d_grid_idx, d_feat,
-                 d_clu, d_grid_C, d_grid_theta, G, d_losses, ctx->d_counter, pre, mfma ? 1 : 0, 0u);
+                 d_clu, d_grid_C, d_grid_theta, G, d_losses, ctx->d_counter, pre, (const int32_t *)nullptr, 0u, 0u);
   }
   HIP_TRY(ctx, hipGetLastError());
   hipLaunchKernelGGL(grid_argmin_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, N, G, d_losses, d_grid_idx,
@@ -2541,7 +2644,7 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
   if (ctx->P.big && grid.x > BIG_MAX_BLOCKS)
     return fail(ctx, NEMO_ERR_UNSUPPORTED, "nemo_grid_prerender: %u (pair, pose) renders with a large mesh (limit %u per call)", grid.x, BIG_MAX_BLOCKS);
   {
-    int rc_ = ensure_big_scratch(ctx, grid.x);
+    int rc_ = reserve_big_scratch(ctx, grid.x);
     if (rc_ != NEMO_OK) return rc_;
   }
   LAUNCH_PB(prerender_kernel, grid, (hipStream_t)stream, ctx->P, ctx->d_meshes, ctx->d_pre_pairs, ctx->d_pre_pairs + n_pairs,
@@ -2553,8 +2656,7 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
   // (uncovered pixels are zero rows).  Skipped when they would not fit the budget (NEMO_PRERENDER_MAP_GB,
   // default 48): the list path above then serves the grid search.
   {
-    const char *env = getenv("NEMO_PRERENDER_MAP_GB");
-    const double budget = (env ? atof(env) : 48.0) * 1073741824.0;
+    const double budget = ctx->env_prerender_map_gb * 1073741824.0;
     const size_t jobs = (size_t)n_pairs * G, D = (size_t)ctx->cfg.feat_dim;
     const double need = (double)jobs * stride * D * 4.0;
     if (need <= budget && n_pairs <= GP_MAX_PAIRS) {
@@ -2596,9 +2698,12 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
 }
 
 // Shared by nemo_solve / nemo_solve6: launch order (longest job first), then the fused solve.
+// `ws` = int32 workspace of 2 * ws_cap entries (cost[ws_cap], order[ws_cap]) -- the context's reservation;
+// never allocated here.
 static int launch_solve(nemo_ctx *ctx, const char *who, int32_t N, const int32_t *d_img_idx, const int32_t *d_mesh_idx,
                         const float *d_feat, const float *d_clu, const float *d_C0, const float *d_theta0,
-                        const float *d_trans0, int ndof, float *d_pose, float *d_loss, float *d_trace, void *stream) {
+                        const float *d_trans0, int ndof, float *d_pose, float *d_loss, float *d_trace, void *stream,
+                        int32_t *ws, size_t ws_cap) {
   int rc = check_ready(ctx, who, N);
   if (rc) return rc > 0 ? NEMO_OK : rc;
   if (ctx->adam_steps <= 0) return fail(ctx, NEMO_ERR_STATE, "%s: call nemo_set_schedule first", who);
@@ -2606,28 +2711,21 @@ static int launch_solve(nemo_ctx *ctx, const char *who, int32_t N, const int32_t
   if (ctx->cfg.clutter && !d_clu) return fail(ctx, NEMO_ERR_ARG, "%s: clutter loss needs d_clu", who);
   if (ctx->P.big && (unsigned)N > BIG_MAX_BLOCKS)
     return fail(ctx, NEMO_ERR_UNSUPPORTED, "%s: %d jobs in one call with a large mesh (limit %u)", who, N, BIG_MAX_BLOCKS);
-  // start stagger in units of (slot x 8128-cycle sleeps): spread ~128 slots over about one step
-  const char *stg = getenv("NEMO_SOLVE_STAGGER");
-  const int stagger = stg ? atoi(stg) : 0;
+  // start stagger (NEMO_SOLVE_STAGGER, experiments) in units of (slot x 8128-cycle sleeps)
+  const int stagger = ctx->env_solve_stagger;
   // launch order: only worth it when some CU gets more than one job (NEMO_SOLVE_ORDER=0 turns it off)
-  const char *ord = getenv("NEMO_SOLVE_ORDER");
   const int32_t *d_order = nullptr;
-  if (N > 64 && !(ord && atoi(ord) == 0)) {
-    if ((size_t)N > ctx->so_cap) {
-      hipFree(ctx->d_so);
-      ctx->d_so = nullptr;
-      ctx->so_cap = 0;
-      HIP_TRY(ctx, hipMalloc((void **)&ctx->d_so, sizeof(int32_t) * 2 * (size_t)N));
-      ctx->so_cap = (size_t)N;
-    }
-    int32_t *d_cost = ctx->d_so, *d_ord = ctx->d_so + ctx->so_cap;
+  if (N > 64 && ctx->env_solve_order) {
+    if ((size_t)N > ws_cap)
+      return fail(ctx, NEMO_ERR_STATE, "%s: launch-order workspace holds %zu jobs, this call has %d: call "
+                  "nemo_workspace_reserve(ctx, >= %d, ...) first", who, ws_cap, N, N);
+    int32_t *d_cost = ws, *d_ord = ws + ws_cap;
     if ((rc = ensure_big_scratch(ctx, (size_t)N)) != NEMO_OK) return rc;
     LAUNCH_PB(solve_cost_kernel, dim3(N), (hipStream_t)stream, ctx->P, ctx->d_meshes, d_mesh_idx, d_C0, d_theta0,
               ndof == 6 ? d_trans0 : (const float *)nullptr, d_cost);
     hipLaunchKernelGGL(solve_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (int)N, (const int32_t *)d_cost, d_ord);
     HIP_TRY(ctx, hipGetLastError());
-    const char *aff = getenv("NEMO_SOLVE_AFFINITY");
-    if (d_mesh_idx && ctx->n_meshes > 1 && !(aff && atoi(aff) == 0)) {
+    if (d_mesh_idx && ctx->n_meshes > 1 && ctx->env_solve_affinity) {
       const int windows = (N + 63) / 64;
       hipLaunchKernelGGL(solve_affinity_kernel, dim3((unsigned)((windows + 63) / 64)), dim3(64), 0, (hipStream_t)stream, (int)N,
                          ctx->n_meshes, d_mesh_idx, d_ord);
@@ -2645,14 +2743,14 @@ int nemo_solve(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t
                const float *d_clu, const float *d_C0, const float *d_theta0, float *d_pose, float *d_loss,
                float *d_trace, void *stream) {
   return launch_solve(ctx, "nemo_solve", N, d_img_idx, d_mesh_idx, d_feat, d_clu, d_C0, d_theta0, nullptr, 4, d_pose,
-                      d_loss, d_trace, stream);
+                      d_loss, d_trace, stream, ctx ? ctx->d_so : nullptr, ctx ? ctx->so_cap : 0);
 }
 
 int nemo_solve6(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t *d_mesh_idx, const float *d_feat,
                 const float *d_clu, const float *d_C0, const float *d_theta0, const float *d_trans0, float *d_pose6,
                 float *d_loss, float *d_trace, void *stream) {
   return launch_solve(ctx, "nemo_solve6", N, d_img_idx, d_mesh_idx, d_feat, d_clu, d_C0, d_theta0, d_trans0, 6, d_pose6,
-                      d_loss, d_trace, stream);
+                      d_loss, d_trace, stream, ctx ? ctx->d_so : nullptr, ctx ? ctx->so_cap : 0);
 }
 
 int nemo_interpolate_backward(nemo_ctx *ctx, const int32_t *d_mesh_idx, const float *d_R, const float *d_T,
@@ -2707,18 +2805,13 @@ int nemo_feature_head(nemo_ctx *ctx, const float *d_x, int32_t N, int32_t C, con
   const size_t lds = (size_t)D * C * sizeof(float);
   if ((C & 1) || lds > 128 * 1024)
     return fail(ctx, NEMO_ERR_UNSUPPORTED, "nemo_feature_head: C = %d (even, D*C*4 <= 128 KiB: the weights are LDS-resident)", C);
-  int n_cu = 256;
-  hipDeviceProp_t prop;
-  int dev = 0;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+  const int n_cu = ctx->n_cu;  // cached by nemo_ctx_create, which also opted the kernel in to 128 KiB of LDS
   const long long tiles = (long long)N * ((hw + 31) / 32);
   const unsigned blocks = (unsigned)(tiles / 4 < n_cu ? (tiles + 3) / 4 : n_cu);
   if (D == 128) {
-    HIP_TRY(ctx, hipFuncSetAttribute((const void *)feature_head_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((feature_head_kernel<128>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, d_x, N, C, hw, d_weight,
                        d_cbank, K, d_feat, d_clu);
   } else {
-    HIP_TRY(ctx, hipFuncSetAttribute((const void *)feature_head_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((feature_head_kernel<256>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, d_x, N, C, hw, d_weight,
                        d_cbank, K, d_feat, d_clu);
   }

@@ -454,6 +454,55 @@ def test_empty_batch_and_errors():
     assert torch.isfinite(loss).all()
 
 
+def test_hot_calls_do_not_allocate():
+    """include/nemo_hip.h: no hot entry point allocates, frees or synchronises.  After nemo_workspace_reserve a
+    first batch (warm-up: code objects, torch's cache) and then a LARGER second batch run through clutter score,
+    grid search (matrix-core and on-the-fly jobs), score and solve without the device's free memory moving, apart
+    from what torch's own allocator takes for the outputs; a batch beyond the reservation is refused with
+    NEMO_ERR_STATE by the C ABI instead of growing the workspace."""
+    import ctypes as C
+    from nemo_amd import _lib
+    from nemo_amd.pose_solver import SolverConfig
+    from nemo_amd.workloads import twelve_class_workload
+    wl = twelve_class_workload(160, seed=3, cfg=SolverConfig(total_epochs=20))
+    s, eng = wl.solver, wl.solver.engine
+    eng.reserve(160, 144)
+    s.prerender()
+
+    def run(n):
+        idx = torch.arange(n, dtype=torch.int32, device='cuda')
+        mesh = wl.mesh_idx[:n].contiguous()
+        gidx = mesh.clone()
+        gidx[::7] = (gidx[::7] + 1) % 12          # (mesh, grid) pairs that were not pre-rendered: grid_kernel's work list
+        clu = eng.clutter_score(wl.feats, wl.clutter)
+        C0, th0, _, _ = eng.grid_search(wl.feats, clu, s.grid_C, s.grid_theta, img_idx=idx, mesh_idx=mesh, grid_idx=gidx)
+        eng.score_fwd_bwd(wl.feats, clu, C0, th0, img_idx=idx, mesh_idx=mesh)
+        return eng.solve(wl.feats, clu, C0, th0, img_idx=idx, mesh_idx=mesh)[0], clu, C0, th0
+
+    def held():  # bytes taken from the device by anyone but torch's caching allocator
+        torch.cuda.synchronize()
+        free, total = torch.cuda.mem_get_info()
+        return total - free - torch.cuda.memory_reserved()
+
+    run(70)
+    base = held()
+    pose, clu, C0, th0 = run(160)
+    assert held() == base and torch.isfinite(pose).all()
+    # beyond the reservation: refused, not grown
+    n = 200
+    idx = (torch.arange(n, device='cuda') % 160).to(torch.int32)
+    mesh = wl.mesh_idx[idx.long()].contiguous()
+    pose, loss = torch.empty(n, 4, device='cuda'), torch.empty(n, device='cuda')
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    rc = eng.lib.nemo_solve(eng.ctx, n, p(idx), p(mesh), p(wl.feats), p(clu), p(C0[idx.long()].contiguous()),
+                            p(th0[idx.long()].contiguous()), p(pose), p(loss), None, eng._stream())
+    assert rc == -3 and b'nemo_workspace_reserve' in eng.lib.nemo_last_error(eng.ctx)
+    losses = torch.empty(n, 144, device='cuda')
+    rc = eng.lib.nemo_grid_search(eng.ctx, n, p(idx), p(mesh), p(mesh), p(wl.feats), p(clu), p(s.grid_C), p(s.grid_theta), 144,
+                                  p(losses), p(pose), p(loss), None, eng._stream())
+    assert rc == -3 and held() == base
+
+
 def test_non_finite_job_is_flagged_not_fatal():
     """A job whose start pose is not finite (the reference scores such solves as pi/2, code/MeshPoseSolveAll.py:262-263)
     comes back non-finite with status 0 in the gathered record; the launch completes and the other jobs of the batch
