@@ -185,6 +185,17 @@ int nemo_solve6(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_
                 const float *d_feat, const float *d_clu, const float *d_C0, const float *d_theta0,
                 const float *d_trans0, float *d_pose6, float *d_loss, float *d_trace, void *stream);
 
+/* nemo_solve for callers that cannot allocate at all (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  It has NO counterpart in the reference.  Same arguments and results as nemo_solve (bit
+ * for bit); the launch-order workspace is a file-scope device array of the library (int32[2 * 16384] = 128 KiB per
+ * GPU, held until the process ends) instead of the context's reservation, so neither this call nor any set-up for
+ * it allocates.  Limits: N <= 16384 (NEMO_ERR_UNSUPPORTED beyond); meshes whose tables do not fit the LDS are
+ * refused (their per-workgroup table scratch is far larger than a static array should be).  Every call on a GPU
+ * shares that GPU's array: calls that overlap on one GPU (two streams, two contexts) race on it. */
+int nemo_solve_static(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t *d_mesh_idx,
+                      const float *d_feat, const float *d_clu, const float *d_C0, const float *d_theta0,
+                      float *d_pose, float *d_loss, float *d_trace, void *stream);
+
 /* Bytes the fused kernels read per covered pixel and step: 4*D + 4. */
 int64_t nemo_bytes_per_covered_pixel(const nemo_ctx *ctx);
 

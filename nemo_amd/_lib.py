@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NEMO_HIP_LIB selects a diagnostic build of the same library (e.g. the phase-stamp build).
 LIB_PATH = os.environ.get('NEMO_HIP_LIB') or os.path.join(_HERE, 'lib', 'libnemo_hip.so')
 
-EXPORTS = ['nemo_ctx_create', 'nemo_ctx_destroy', 'nemo_last_error', 'nemo_mesh_register', 'nemo_workspace_reserve',
+EXPORTS = ['nemo_ctx_create', 'nemo_ctx_destroy', 'nemo_last_error', 'nemo_mesh_register', 'nemo_workspace_reserve', 'nemo_solve_static',
            'nemo_set_schedule', 'nemo_campos_to_R_T', 'nemo_rasterize', 'nemo_interpolate',
            'nemo_interpolate_backward', 'nemo_clutter_score', 'nemo_score_fwd_bwd',
            'nemo_grid_search', 'nemo_grid_prerender', 'nemo_solve', 'nemo_solve6', 'nemo_feature_head', 'nemo_bytes_per_covered_pixel', 'nemo_counter_reset',
@@ -59,6 +59,7 @@ def load():
     lib.nemo_grid_search.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     lib.nemo_grid_prerender.argtypes = [vp, vp, vp, i32, i32, vp, vp, i32, vp]
     lib.nemo_solve.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.nemo_solve_static.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.nemo_workspace_reserve.argtypes = [vp, i32, i32]
     lib.nemo_feature_head.argtypes = [vp, vp, i32, i32, vp, vp, i32, vp, vp, vp]
     lib.nemo_solve6.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]

@@ -19,6 +19,7 @@
 // explicit fmaf.  Reference citations (file:line) are into Angtian/NeMo.
 
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <vector>
 #include <math.h>
 #include <stdarg.h>
@@ -2233,6 +2234,27 @@ static int ensure_big_scratch(nemo_ctx *ctx, size_t nblocks) {
   return NEMO_OK;
 }
 
+// ---- nemo_solve_static: the solve's launch-order workspace in a file-scope device array instead of context
+// memory, for callers that cannot allocate (HIP graph capture, serving loops).  Each GPU the library runs on holds
+// its own copy of the array at its own address; the address is looked up once per device (static_ws_init, from
+// nemo_ctx_create with that device current) and only that pointer -- never the array's name -- is used on the host.
+constexpr int STATIC_MAX_JOBS = 16384;  // 2 x 16384 x 4 B = 128 KiB per GPU, held until the process ends
+static __device__ __align__(256) int32_t scratch[2 * STATIC_MAX_JOBS];
+constexpr int MAX_DEVICES = 64;
+static int32_t *g_static_ws[MAX_DEVICES];
+static std::mutex g_static_mu;
+static int static_ws_init(nemo_ctx *ctx) {
+  const int dev = ctx->device;
+  if (dev < 0 || dev >= MAX_DEVICES) return NEMO_OK;  // nemo_solve_static refuses such a device
+  std::lock_guard<std::mutex> lock(g_static_mu);
+  if (!g_static_ws[dev]) {
+    void *ptr = nullptr;
+    HIP_TRY(ctx, hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    g_static_ws[dev] = (int32_t *)ptr;
+  }
+  return NEMO_OK;
+}
+
 #define DISPATCH_DPB(kern, BIGV, grid, ...)                                                                       \
   do {                                                                                                            \
     const bool persp_ = ctx->P.persp != 0;                                                                        \
@@ -2344,6 +2366,8 @@ int nemo_ctx_create(const nemo_config *cfg, nemo_ctx **out) {
     const char *v = getenv("NEMO_PRERENDER_MAP_GB");
     ctx->env_prerender_map_gb = v ? atof(v) : 48.0;
   }
+  rc = static_ws_init(ctx);
+  if (rc != NEMO_OK) { nemo_ctx_destroy(ctx); return rc; }
   *out = ctx;
   return NEMO_OK;
 }
@@ -2697,9 +2721,9 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
   return NEMO_OK;
 }
 
-// Shared by nemo_solve / nemo_solve6: launch order (longest job first), then the fused solve.
-// `ws` = int32 workspace of 2 * ws_cap entries (cost[ws_cap], order[ws_cap]) -- the context's reservation;
-// never allocated here.
+// Shared by nemo_solve / nemo_solve6 / nemo_solve_static: launch order (longest job first), then the fused solve.
+// `ws` = int32 workspace of 2 * ws_cap entries (cost[ws_cap], order[ws_cap]) -- the context's reservation or the
+// static device array; never allocated here.
 static int launch_solve(nemo_ctx *ctx, const char *who, int32_t N, const int32_t *d_img_idx, const int32_t *d_mesh_idx,
                         const float *d_feat, const float *d_clu, const float *d_C0, const float *d_theta0,
                         const float *d_trans0, int ndof, float *d_pose, float *d_loss, float *d_trace, void *stream,
@@ -2744,6 +2768,21 @@ int nemo_solve(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t
                float *d_trace, void *stream) {
   return launch_solve(ctx, "nemo_solve", N, d_img_idx, d_mesh_idx, d_feat, d_clu, d_C0, d_theta0, nullptr, 4, d_pose,
                       d_loss, d_trace, stream, ctx ? ctx->d_so : nullptr, ctx ? ctx->so_cap : 0);
+}
+
+int nemo_solve_static(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t *d_mesh_idx, const float *d_feat,
+                      const float *d_clu, const float *d_C0, const float *d_theta0, float *d_pose, float *d_loss,
+                      float *d_trace, void *stream) {
+  if (!ctx) return fail(nullptr, NEMO_ERR_ARG, "nemo_solve_static: null ctx");
+  if (N > STATIC_MAX_JOBS)
+    return fail(ctx, NEMO_ERR_UNSUPPORTED, "nemo_solve_static: %d jobs, the static workspace holds %d", N, STATIC_MAX_JOBS);
+  if (ctx->P.big)
+    return fail(ctx, NEMO_ERR_UNSUPPORTED, "nemo_solve_static: large meshes need per-workgroup table scratch "
+                "(use nemo_workspace_reserve + nemo_solve)");
+  int32_t *ws = (ctx->device >= 0 && ctx->device < MAX_DEVICES) ? g_static_ws[ctx->device] : nullptr;
+  if (!ws) return fail(ctx, NEMO_ERR_STATE, "nemo_solve_static: no static workspace on device %d", ctx->device);
+  return launch_solve(ctx, "nemo_solve_static", N, d_img_idx, d_mesh_idx, d_feat, d_clu, d_C0, d_theta0, nullptr, 4, d_pose,
+                      d_loss, d_trace, stream, ws, (size_t)STATIC_MAX_JOBS);
 }
 
 int nemo_solve6(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t *d_mesh_idx, const float *d_feat,
