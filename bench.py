@@ -7,15 +7,20 @@ vertex features, 144-pose grid init + 300 Adam steps per image).
 
 One "step" = one pass of the hot path over the batch: clutter score -> pose-grid
 search -> fused 300-step solve -> decode (+ one RCCL all-gather of the poses when
-N > 1).  Inputs are resident in HBM before the timed region.  For N > 1 launch
-with torch.distributed.run (one rank per GPU); images are sharded per rank (weak
-scaling), no collective on the data path.  Rank 0 prints ONE JSON line.
+N > 1).  Inputs are resident in HBM before the timed region.  For N > 1 there is
+one rank per GPU: either the caller starts them (python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N ...) or, when WORLD_SIZE is not set, this
+script starts that launcher itself as a child process -- before anything here
+touches a GPU -- and relays rank 0's JSON line and the exit code.  Images are
+sharded per rank (weak scaling), no collective on the data path.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -67,6 +72,20 @@ def cpu_baseline(wl, n_sample):
                       f'{dt:.1f} s wall; host has {os.cpu_count()} logical CPUs'}
 
 
+def launch_ranks(n_gpus, argv):
+    """`bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+    as a CHILD (the one-command multi-GPU entry, as the reference's InferenceNeMo.sh:42-50,67-81 is one command).
+    Called before this process has made any GPU call; nothing is exec'ed."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n_gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
+
+
 def pmc_traffic(cov_steps):
     """HBM bytes per launch of the solve kernel from the committed PMC passes (profiles/r01_pmc_traffic.json:
     rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate runs of this workload, FETCH_SIZE doubled as the
@@ -88,53 +107,58 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--images', type=int, default=1024, help='images per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='process-group backend for N > 1: nccl = RCCL over xGMI (the product path); gloo = rehearsal of the '
+                         'multi-rank code on a box with fewer GPUs than ranks (records gathered through host memory)')
+    ap.add_argument('--share-gpu', action='store_true', help='rehearsal only: every rank uses GPU 0 (needs --backend gloo)')
     ap.add_argument('--cpu-sample', type=int, default=0, help='images in the CPU baseline sample (0 = 3 per host thread, at most 16 threads: about 13 s)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world != args.gpus:
-        print(f'bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})',
-              file=sys.stderr)
+        print(f'bench.py: --gpus {args.gpus} but the launcher started {world} ranks', file=sys.stderr)
         sys.exit(2)
+    if not torch.cuda.is_available():
+        print(f'bench.py (rank {rank}): no GPU visible; the pose-solve path has no CPU fallback', file=sys.stderr)
+        sys.exit(3)
+    if args.share_gpu:
+        if world > 1 and args.backend != 'gloo':
+            print('bench.py: --share-gpu needs --backend gloo (RCCL refuses two ranks on one GPU)', file=sys.stderr)
+            sys.exit(2)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group('gloo')
+    from nemo_amd import distributed as nd
 
     from nemo_amd.workloads import twelve_class_workload
     wl = twelve_class_workload(args.images, seed=1000 + rank, device=dev)
     solver, eng = wl.solver, wl.solver.engine
-    gathered = torch.empty((world * args.images, 8), device=dev) if world > 1 else None
+    eng.reserve(args.images, int(solver.grid_theta.shape[1]))  # set-up: the timed calls allocate nothing in the library
 
     def step():
         res = solver.solve_all(wl.feats, wl.clutter, wl.mesh_idx)
-        rec = res.packed()
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, rec)
+        nd.gather_records(res.packed(), world * args.images)  # the path's one collective: [B, 8] records over RCCL
         return res
-
-    def fence():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
         step()
-    fence()
+    nd.fence(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    nd.fence(dev)
+    dt = nd.max_over_ranks(time.perf_counter() - t0, dev)
 
     # ---- dominant kernel (fused solve) timed alone with HIP events on the launch stream
     clu = eng.clutter_score(wl.feats, wl.clutter)
@@ -166,7 +190,7 @@ def main():
             'metric': 'pose solves/sec (300 Adam iters, whole node)',
             'value': world * args.images * args.steps / dt,
             'unit': 'solves/s',
-            'n_gpus': world,
+            'n_gpus': world if not args.share_gpu else 1,
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': 1e3 * dt / args.steps,
@@ -177,7 +201,8 @@ def main():
             'data': 'synthetic',
             'config': {'workload': wl.name, 'images_per_gpu': args.images, 'feature_map': [eng.h, eng.w, eng.D],
                        'raster': eng.S, 'grid_poses': int(solver.grid_theta.shape[1]),
-                       'adam_steps': solver.cfg.total_epochs, 'parallelism': f'images sharded over {world} GPU(s)'},
+                       'adam_steps': solver.cfg.total_epochs, 'parallelism': f'images sharded over {world} GPU(s)'
+                       + (f' [REHEARSAL: {world} ranks share one GPU, gloo]' if args.share_gpu else '')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(cov_steps), 'kernel': 'solve_kernel',
                          'kernel_ms': solve_ms, 'algorithmic_bytes_per_launch': alg_bytes,

@@ -28,15 +28,40 @@ def gather_records(local: torch.Tensor, n_total: int, group=None) -> torch.Tenso
     world = dist.get_world_size(group)
     width = local.shape[1]
     per = -(-n_total // world)
-    pad = torch.zeros((per, width), dtype=local.dtype, device=local.device)
+    # RCCL ("nccl") gathers device tensors in place; a gloo group (CPU tests, single-GPU rehearsals) goes
+    # through host memory
+    home = local.device
+    work = torch.device('cpu') if (dist.get_backend(group) == 'gloo' and local.is_cuda) else home
+    pad = torch.zeros((per, width), dtype=local.dtype, device=work)
     pad[:local.shape[0]] = local
-    out = torch.empty((world * per, width), dtype=local.dtype, device=local.device)
+    out = torch.empty((world * per, width), dtype=local.dtype, device=work)
     dist.all_gather_into_tensor(out, pad, group=group)
     rows = []
     for r in range(world):
         s, e = shard_range(n_total, r, world)
         rows.append(out[r * per:r * per + (e - s)])
-    return torch.cat(rows, dim=0)
+    return torch.cat(rows, dim=0).to(home)
+
+
+def max_over_ranks(value: float, device=None, group=None) -> float:
+    """Largest `value` over the ranks (bench.py times a step as long as its slowest rank)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return float(value)
+    on_cpu = device is None or dist.get_backend(group) == 'gloo'
+    t = torch.tensor([value], dtype=torch.float64, device='cpu' if on_cpu else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
+
+
+def fence(device=None, group=None):
+    """Device synchronise + barrier + synchronise: the bracket bench.py puts around its timed region."""
+    cuda = device is not None and torch.device(device).type == 'cuda'
+    if cuda:
+        torch.cuda.synchronize(device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.barrier(group=group)
+        if cuda:
+            torch.cuda.synchronize(device)
 
 
 def solve_sharded(solve_fn, n_images: int, group=None) -> torch.Tensor:

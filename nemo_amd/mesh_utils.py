@@ -172,13 +172,22 @@ class _RenderInterpolate(torch.autograd.Function):
         return gR, gT, None, None
 
 
+def _pack_face_ids(p2f, n_faces, mesh_idx):
+    """PyTorch3D returns PACKED face ids (batch element n offset by the faces of the elements before it,
+    SURVEY 8a row P4); the kernels return ids local to the job's mesh."""
+    n = p2f.shape[0]
+    nf = torch.as_tensor(n_faces, dtype=torch.int64, device=p2f.device)
+    per = nf[mesh_idx.long()] if mesh_idx is not None else nf[:1].expand(n)
+    off = torch.cumsum(per, 0) - per
+    p2f = p2f.long()
+    return torch.where(p2f >= 0, p2f + off.view(n, 1, 1), p2f)
+
+
 class MeshInterpolateModule(nn.Module):
     """lib/MeshUtils.py:153-227.  forward(campos [n,3], theta [n]) -> [n, D, h, w]."""
 
     def __init__(self, vertices, faces, memory_bank, rasterizer, post_process=None, off_set_mesh=False):
         super().__init__()
-        if off_set_mesh:
-            raise NotImplementedError('deform_verts / off_set_mesh is not on the MeshPoseSolveAll path')
         self.rasterizer = rasterizer
         self.post_process = post_process
         self.off_set_mesh = off_set_mesh
@@ -234,19 +243,172 @@ class MeshInterpolateModule(nn.Module):
     def forward(self, campos, theta, blur_radius=0, deform_verts=None, mode='bilinear', **kwargs):
         if self.engine is None:
             raise RuntimeError('MeshInterpolateModule must be moved to a GPU first (.cuda()); there is no CPU path')
-        if blur_radius != 0 or deform_verts is not None or mode != 'bilinear':
-            raise NotImplementedError('blur_radius > 0, deform_verts and mode="nearest" are not on the solver path')
+        if blur_radius != 0:
+            raise NotImplementedError('blur_radius > 0 (soft rasterization) is not on the solver path')
+        if mode not in ('bilinear', 'nearest'):
+            raise ValueError('mode must be "bilinear" or "nearest"')
         R, T = campos_to_R_T(campos, theta, device=campos.device, **kwargs)
-        n_cam = campos.shape[0]
-        if n_cam > 1 and self.n_mesh > 1:
+        mesh_idx = self._mesh_idx(campos.shape[0], campos.device)
+        self._apply_offsets(deform_verts)
+        if mode == 'nearest':
+            # lib/MeshUtils.py:126-127: barycentrics replaced by the one-hot of their arg-max; the scatter cuts the
+            # autograd graph in the reference as well, so this mode carries no pose gradient
+            with torch.no_grad():
+                p2f, bary = self.engine.rasterize(R.detach().contiguous(), T.detach().contiguous(), mesh_idx)
+                hot = torch.where((p2f >= 0)[..., None], set_bary_coords_to_nearest(bary), bary)
+                return self.engine.interpolate(p2f, hot.contiguous(), mesh_idx).permute(0, 3, 1, 2)
+        return _RenderInterpolate.apply(R, T, self.engine, mesh_idx)
+
+    def _mesh_idx(self, n_cam, device):
+        if n_cam > 1 and self.n_mesh > 1:                 # one camera per mesh (:218-219)
             if n_cam != self.n_mesh:
                 raise ValueError('one camera per mesh expected')
-            mesh_idx = torch.arange(n_cam, dtype=torch.int32, device=campos.device)
-        else:
-            mesh_idx = None  # one mesh, n cameras (the reference extends the mesh, :220-221)
-        return _RenderInterpolate.apply(R, T, self.engine, mesh_idx)
+            return torch.arange(n_cam, dtype=torch.int32, device=device)
+        if self.n_mesh > 1:
+            raise ValueError('a module holding several meshes needs one camera per mesh')
+        return None                                       # one mesh, n cameras (the reference extends the mesh, :220-221)
+
+    def _apply_offsets(self, deform_verts):
+        """off_set_mesh (lib/MeshUtils.py:212-213): meshes.offset_verts(deform_verts) moves the packed vertices
+        before rendering.  Forward only: the kernels have no dL/d(vertex) output, so a deformation that requires
+        grad is refused."""
+        if not self.off_set_mesh:
+            return
+        if deform_verts is None:
+            raise ValueError('off_set_mesh=True needs deform_verts')
+        if deform_verts.requires_grad:
+            raise NotImplementedError('gradients with respect to deform_verts are not implemented')
+        start = 0
+        for (v_dev, _, _), base in zip(self.engine._keep, self._verts):
+            n = base.shape[0]
+            v_dev.copy_(base.to(v_dev.device, torch.float32) + deform_verts[start:start + n].to(v_dev.device, torch.float32))
+            start += n
 
     # extras for callers that want the fragments (rasterize / forward_interpolate of the reference)
     def fragments(self, R, T, mesh_idx=None):
+        """Fragments of rasterize (lib/MeshUtils.py:83-85) in PyTorch3D's shapes; pix_to_face holds PACKED ids."""
+        if mesh_idx is None:
+            mesh_idx = self._mesh_idx(R.shape[0], R.device)
         p2f, bary, zb = self.engine.rasterize(R.contiguous(), T.contiguous(), mesh_idx, want_zbuf=True)
-        return Fragments(pix_to_face=p2f.long()[..., None], zbuf=zb[..., None], bary_coords=bary[:, :, :, None, :])
+        packed = _pack_face_ids(p2f, [int(f.shape[0]) for f in self._faces], mesh_idx)
+        return Fragments(pix_to_face=packed[..., None], zbuf=zb[..., None], bary_coords=bary[:, :, :, None, :])
+
+
+# ----------------------------------------------------------------------------- free functions of the reference module
+class Meshes:
+    """Holder with the part of PyTorch3D's Meshes the reference touches (lib/MeshUtils.py:168,176,213,221):
+    lists of PRE-PROCESSED vertices and faces, `extend`, `offset_verts`, `to`."""
+
+    def __init__(self, verts, faces, textures=None):
+        self._verts = [torch.as_tensor(v, dtype=torch.float32) for v in verts]
+        self._faces = [torch.as_tensor(f) for f in faces]
+        self._engines = {}
+
+    def __len__(self):
+        return len(self._verts)
+
+    def verts_list(self):
+        return self._verts
+
+    def faces_list(self):
+        return self._faces
+
+    def verts_packed(self):
+        return torch.cat(self._verts, 0)
+
+    def extend(self, n):
+        return Meshes([v for v in self._verts for _ in range(n)], [f for f in self._faces for _ in range(n)])
+
+    def offset_verts(self, offsets):
+        out, start = [], 0
+        for v in self._verts:
+            out.append(v + offsets[start:start + v.shape[0]].to(v.device))
+            start += v.shape[0]
+        return Meshes(out, self._faces)
+
+    def to(self, device):
+        return Meshes([v.to(device) for v in self._verts], [f.to(device) for f in self._faces])
+
+    def cuda(self):
+        return self.to('cuda')
+
+
+def _engine_for(meshes: Meshes, rasterizer: MeshRasterizer, face_memory=None):
+    """One PoseEngine per (Meshes object, raster settings, face memory): rendering the full S x S square, with
+    `face_memory` [sum F, 3, D] presented to the kernels as a bank of 3 F rows indexed by faces (3f, 3f+1, 3f+2)."""
+    rs = rasterizer.raster_settings
+    if rs.blur_radius != 0 or rs.faces_per_pixel != 1 or rs.bin_size not in (0, None):
+        raise NotImplementedError('only blur_radius=0, faces_per_pixel=1, naive rasterization is implemented')
+    key = (int(rs.image_size), float(rasterizer.cameras.fov), bool(getattr(rs, 'perspective_correct', False)),
+           None if face_memory is None else (face_memory.data_ptr(), face_memory._version, tuple(face_memory.shape)))
+    eng = meshes._engines.get(key)
+    if eng is None:
+        dev = meshes._verts[0].device
+        D = 128 if face_memory is None else int(face_memory.shape[-1])
+        S = key[0]
+        eng = PoseEngine(S, (S, S), D, fov=key[1], perspective_correct=key[2], device=dev, crop_origin=(0, 0))
+        start = 0
+        for v, f in zip(meshes._verts, meshes._faces):
+            F_ = int(f.shape[0])
+            if face_memory is None:
+                eng.register_mesh(v, f, torch.zeros((v.shape[0], D), device=dev))
+            else:  # corner c of face f reads row 3 f + c of the flattened face memory
+                corner = torch.arange(3 * F_, device=dev, dtype=torch.int32).view(F_, 3)
+                bank = face_memory[start:start + F_].reshape(3 * F_, D).to(dev, torch.float32).contiguous()
+                vv = v.to(dev)[f.long().to(dev)].reshape(3 * F_, 3).contiguous()
+                eng.register_mesh(vv, corner, bank)
+            start += F_
+        meshes._engines[key] = eng
+    return eng
+
+
+def rasterize(R, T, meshes, rasterizer, blur_radius=0):
+    """lib/MeshUtils.py:83-101 (blur_radius = 0): Fragments of the full S x S render, one batch element per mesh
+    of `meshes` (extend(n) for n cameras on one mesh), packed face ids."""
+    if blur_radius > 0:
+        raise NotImplementedError('blur_radius > 0 (soft rasterization) is not on the solver path')
+    eng = _engine_for(meshes, rasterizer)
+    n = R.shape[0]
+    if n != len(meshes):
+        raise ValueError('%d cameras for %d meshes (use meshes.extend(n))' % (n, len(meshes)))
+    mesh_idx = torch.arange(n, dtype=torch.int32, device=R.device)
+    p2f, bary, zb = eng.rasterize(R.detach().contiguous(), T.detach().contiguous(), mesh_idx, want_zbuf=True)
+    packed = _pack_face_ids(p2f, [int(f.shape[0]) for f in meshes._faces], mesh_idx)
+    return Fragments(pix_to_face=packed[..., None], zbuf=zb[..., None], bary_coords=bary[:, :, :, None, :])
+
+
+def forward_interpolate(R, T, meshes, face_memory, rasterizer, blur_radius=0, mode='bilinear'):
+    """lib/MeshUtils.py:122-133 -> [n, D, S, S]; differentiable in (R, T) for mode='bilinear'."""
+    if blur_radius > 0:
+        raise NotImplementedError('blur_radius > 0 (soft rasterization) is not on the solver path')
+    eng = _engine_for(meshes, rasterizer, face_memory)
+    n = R.shape[0]
+    if n != len(meshes):
+        raise ValueError('%d cameras for %d meshes (use meshes.extend(n))' % (n, len(meshes)))
+    mesh_idx = torch.arange(n, dtype=torch.int32, device=R.device)
+    if mode == 'nearest':
+        with torch.no_grad():
+            p2f, bary = eng.rasterize(R.detach().contiguous(), T.detach().contiguous(), mesh_idx)
+            hot = torch.where((p2f >= 0)[..., None], set_bary_coords_to_nearest(bary), bary)
+            return eng.interpolate(p2f, hot.contiguous(), mesh_idx).permute(0, 3, 1, 2)
+    return _RenderInterpolate.apply(R, T, eng, mesh_idx)
+
+
+def angel_gradient_modifier(base, grad_=None, alpha=(1.0, 1.0), center_=None):
+    """lib/MeshUtils.py:237-261 (unused by the solver; commented out at code/MeshPoseSolveAll.py:241-242): rescales
+    the radial and tangential parts of a camera-position gradient by alpha[0] / alpha[1]."""
+    write_back = grad_ is None
+    g = base.grad if write_back else grad_
+    rel = base.detach() - center_ if center_ is not None else base.detach()
+    with torch.no_grad():
+        unit = rel / rel.pow(2).sum(dim=1).sqrt()
+        radial = (unit * g).sum(dim=1, keepdim=True) * unit
+        out = alpha[0] * radial + alpha[1] * (g - radial)
+    if write_back:
+        base.grad = out
+    return out
+
+
+def decompose_pose(pose, sorts=('distance', 'elevation', 'azimuth', 'theta')):
+    """lib/MeshUtils.py:264-266."""
+    return tuple(pose[:, sorts.index(k)] for k in ('distance', 'elevation', 'azimuth', 'theta'))

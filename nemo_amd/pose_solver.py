@@ -168,12 +168,35 @@ class BatchPoseSolver:
         """normalize(mean(clutter_bank, 0)) (code/MeshPoseSolveAll.py:207) -> [1, D]."""
         return normalize(torch.mean(clutter_bank, dim=0)).unsqueeze(0).contiguous()
 
-    def solve_all(self, feats: torch.Tensor, clutter: torch.Tensor, mesh_idx: Optional[torch.Tensor] = None,
-                  img_idx: Optional[torch.Tensor] = None, want_trace=False) -> SolveResult:
+    def clutter_scores_by_group(self, feats: torch.Tensor, group_of_image: Sequence[int],
+                                clutter_of_group: Sequence[torch.Tensor]) -> torch.Tensor:
+        """Clutter score maps [n_img,h,w] when images of different subtypes use different clutter banks
+        (code/MeshPoseSolveAll.py:203-207 reads `clutter_<subtype>` inside the subtype loop): images are
+        scored in runs of equal group, each run against its own [K,D] bank."""
+        g = np.asarray(group_of_image)
+        clu = torch.empty((feats.shape[0], self.geo.h, self.geo.w), dtype=torch.float32, device=self.device)
+        start = 0
+        while start < len(g):
+            stop = start + 1
+            while stop < len(g) and g[stop] == g[start]:
+                stop += 1
+            clu[start:stop] = self.engine.clutter_score(feats[start:stop], clutter_of_group[int(g[start])])
+            start = stop
+        return clu
+
+    def solve_all(self, feats: torch.Tensor, clutter: Optional[torch.Tensor], mesh_idx: Optional[torch.Tensor] = None,
+                  img_idx: Optional[torch.Tensor] = None, want_trace=False,
+                  clutter_scores: Optional[torch.Tensor] = None) -> SolveResult:
         """feats [n_img,h,w,D] pixel-major f32 on the device; clutter [K,D] (K=1: the reference's
-        mean vector); jobs default to image i with mesh mesh_idx[i]."""
+        mean vector; K>1: max over the K vectors, lib/MeshUtils.py:273-275) or, instead, ready-made
+        clutter_scores [n_img,h,w] (clutter_scores_by_group); jobs default to image i with mesh mesh_idx[i]."""
         eng = self.engine
-        clu = None if self.cfg.turn_off_clutter else eng.clutter_score(feats, clutter)
+        if self.cfg.turn_off_clutter:
+            clu = None
+        elif clutter_scores is not None:
+            clu = clutter_scores
+        else:
+            clu = eng.clutter_score(feats, clutter)
         n_jobs = img_idx.shape[0] if img_idx is not None else feats.shape[0]
         self.prerender()
         C0, th0, best, _ = eng.grid_search(feats, clu, self.grid_C, self.grid_theta, n_jobs=n_jobs,

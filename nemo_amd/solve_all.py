@@ -6,7 +6,8 @@ of ExtractFeatures.py, the category's CAD .off meshes, per-image annotation .npz
 (`--save_accuracy` record for CalAccuracy.py, or the Thr / Med lines on stdout, :273-287).  The per-image
 Python loop (:217-271) is replaced by clutter score -> pre-rendered grid search -> fused solve over all
 images of the category at once; under `python -m torch.distributed.run` the images are sharded over ranks
-and the error lists gathered on rank 0 (InferenceNeMo.sh's per-category processes + file merge).
+and the [n, 10] pose records come back through ONE all-gather (nemo_amd.distributed.gather_records; names go by
+index), which replaces InferenceNeMo.sh's per-category processes + file merge; rank 0 scores them.
 
 `python -m nemo_amd.solve_all --accuracy_table DIR` is code/CalAccuracy.py.
 """
@@ -59,43 +60,83 @@ def record_path(args):
     return os.path.join(args.feature_path, args.type_, name)
 
 
-def solve_category(args, device='cuda:0', rank=0, world=1):
+RECORD_WIDTH = 10  # SolveResult.packed() (dist, elev, azim, theta, loss, init, status, pad) + trans_2d (6-DoF, else 0)
+
+
+def category_jobs(rec, subtypes):
+    """Image names and their subtype index, in record order (code/MeshPoseSolveAll.py:199,217)."""
+    names, mesh_of = [], []
+    for k, st in enumerate(subtypes):
+        for n in rec.names(st):
+            names.append(n)
+            mesh_of.append(k)
+    return names, mesh_of
+
+
+def build_solver(args, rec, subtypes, device):
+    """Cameras, rasterizer settings, one mesh + bank + pose grid + clutter vector per subtype (:180-207)."""
     cate = args.type_
     image_size = tuple(int(v) for v in args.image_size.split(',')) if args.image_size else syn.IMAGE_SIZES[cate]
     mesh_dir = args.mesh_path % (args.mesh_d, cate) if args.mesh_path.count('%s') == 2 else args.mesh_path
-    anno_dir = args.anno_path % cate if '%s' in args.anno_path else args.anno_path
     kw = dict(image_size=image_size, feat_dim=args.feat_dim, total_epochs=args.total_epochs, lr=args.lr,
               adam_beta_0=args.adam_beta_0, adam_beta_1=args.adam_beta_1, turn_off_clutter=args.turn_off_clutter)
     cfg = SolverConfig.unlabeled_6dof(**kw) if args.six_dof else SolverConfig(**kw)
     solver = BatchPoseSolver(cfg, device)
+    clutter = []
+    for k, st in enumerate(subtypes):                                              # :199-207
+        xvert, xface = load_off(os.path.join(mesh_dir, '%02d.off' % (k + 1)))
+        solver.add_mesh(xvert, xface, rec.memory(st), syn.DISTANCE_RENDER[cate])
+        # the clutter vector is per subtype: `clutter_<subtype>` is read inside the subtype loop (:203,207)
+        clutter.append(solver.clutter_vector(torch.from_numpy(rec.clutter(st)).to(solver.device)))
+    return solver, clutter
+
+
+def solve_shard(args, rec, subtypes, names, mesh_of, device):
+    """Clutter score (per subtype) -> grid init -> fused solve for the listed images: [len(names), 10] records."""
+    solver, clutter = build_solver(args, rec, subtypes, device)
+    feats = rec.upload_pixel_major(names, solver.device)
+    clu = None if solver.cfg.turn_off_clutter else solver.clutter_scores_by_group(feats, mesh_of, clutter)
+    mesh_idx = torch.tensor(mesh_of, dtype=torch.int32, device=solver.device)
+    res = solver.solve_all(feats, None, mesh_idx, clutter_scores=clu)
+    t2 = res.trans_2d if res.trans_2d is not None else torch.zeros((len(names), 2), device=solver.device)
+    return torch.cat([res.packed(), t2], dim=1), dict(solver=solver, result=res, clu=clu, feats=feats)
+
+
+def run_sharded(n_items, solve_fn, device):
+    """The multi-GPU layout of the path (InferenceNeMo.sh:42-50,67-81 replaced): this rank's contiguous
+    shard is solved by solve_fn(start, stop) -> [stop-start, W] records, one all-gather of the records returns
+    all of them, in item order, on every rank.  No collective on the data path."""
+    import torch.distributed as dist
+    from .distributed import gather_records, shard_range
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    lo, hi = shard_range(n_items, rank, world)
+    local = solve_fn(lo, hi) if hi > lo else torch.zeros((0, RECORD_WIDTH), dtype=torch.float32, device=device)
+    return gather_records(local.to(device), n_items)
+
+
+def solve_category(args, device='cuda:0'):
+    """-> (names, [n, 10] records of every image of the category, on the host)."""
+    cate = args.type_
+    mesh_dir = args.mesh_path % (args.mesh_d, cate) if args.mesh_path.count('%s') == 2 else args.mesh_path
     n_mesh = len([f for f in os.listdir(mesh_dir) if f.endswith('.off')])
     subtypes = ['mesh%02d' % i for i in range(1, 1 + n_mesh)]                      # :172
     with records.FeatureRecord(record_path(args)) as rec:
-        names, mesh_of = [], []
-        clutter = None
-        for k, st in enumerate(subtypes):                                          # :199-207
-            xvert, xface = load_off(os.path.join(mesh_dir, '%02d.off' % (k + 1)))
-            solver.add_mesh(xvert, xface, rec.memory(st), syn.DISTANCE_RENDER[cate])
-            if clutter is None:
-                clutter = solver.clutter_vector(torch.from_numpy(rec.clutter(st)).to(solver.device))
-            for n in rec.names(st):
-                names.append(n)
-                mesh_of.append(k)
-        lo, hi = (len(names) * rank) // world, (len(names) * (rank + 1)) // world  # contiguous image shard
-        my_names, my_mesh = names[lo:hi], mesh_of[lo:hi]
-        feats = rec.upload_pixel_major(my_names, solver.device) if my_names else None
-    if not my_names:
-        return [], [], np.zeros((0, 6), np.float32)
-    mesh_idx = torch.tensor(my_mesh, dtype=torch.int32, device=solver.device)
-    res = solver.solve_all(feats, clutter, mesh_idx)
-    theta, dist, elev, azim = (t.cpu().numpy() for t in (res.theta, res.distance, res.elevation, res.azimuth))
+        names, mesh_of = category_jobs(rec, subtypes)
+        recs = run_sharded(len(names), lambda lo, hi: solve_shard(args, rec, subtypes, names[lo:hi], mesh_of[lo:hi], device)[0],
+                           device)
+    return names, mesh_of, recs.cpu().numpy()
+
+
+def errors_from_records(names, recs, anno_dir):
+    """code/MeshPoseSolveAll.py:256-271 from the gathered records (columns: dist, elev, azim, theta)."""
     errors, cads = [], []
     if anno_dir and os.path.isdir(anno_dir):
-        for i, n in enumerate(my_names):                                           # :256-271
+        for i, n in enumerate(names):
             a = records.load_annotation(os.path.join(anno_dir, n + '.npz'))
-            errors.append(records.rotation_error(a, theta[i], elev[i], azim[i], dist[i]))
+            errors.append(records.rotation_error(a, recs[i, 3], recs[i, 1], recs[i, 2], recs[i, 0]))
             cads.append(a.cad_index)
-    return my_names, list(zip(errors, cads)), res.preds6().cpu().numpy()
+    return errors, cads
 
 
 def main(argv=None):
@@ -110,23 +151,20 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group('nccl' if torch.cuda.is_available() else 'gloo')
-    names, errs, preds = solve_category(args, 'cuda:%d' % local, rank, world)
+    names, _, recs = solve_category(args, 'cuda:%d' % local)
     if world > 1:
         import torch.distributed as dist
-        gathered = [None] * world
-        dist.all_gather_object(gathered, (names, errs, preds))
-        names = [n for g in gathered for n in g[0]]
-        errs = [e for g in gathered for e in g[1]]
-        preds = np.concatenate([g[2] for g in gathered], 0)
         dist.destroy_process_group()
     if rank != 0:
         return 0
+    anno_dir = args.anno_path % args.type_ if '%s' in args.anno_path else args.anno_path
     if args.save_final_pred:                                                       # PredUnlabeledDataset.py:344-352
         os.makedirs(os.path.dirname(os.path.abspath(args.save_final_pred)), exist_ok=True)
+        preds = recs[:, [0, 3, 1, 2, 8, 9]]                                        # distance, theta, elevation, azimuth, t0, t1
         np.savez(args.save_final_pred, **{n: preds[i] for i, n in enumerate(names)})
-    total_error = [e for e, _ in errs]
+    total_error, cads = errors_from_records(names, recs, anno_dir)
     if args.save_accuracy:                                                         # :273-274
-        records.save_category_errors(args.save_accuracy, total_error, [c for _, c in errs])
+        records.save_category_errors(args.save_accuracy, total_error, cads)
     elif total_error:                                                              # :275-287
         te = np.asarray(total_error)
         for thr in (np.pi / 6, np.pi / 18):

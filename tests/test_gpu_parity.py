@@ -203,6 +203,33 @@ def test_clutter_score(oracle, K):
         assert np.abs(out[i] - ref).max() <= 2e-6  # fp32 fmaf chain vs double accumulation, |x| <= 1
 
 
+@pytest.mark.parametrize('K', [1, 64, 2560])
+def test_clutter_score_256d_double_resolution(oracle, K):
+    """BASELINE config 5's clutter half: K-vector bank, max over K (lib/MeshUtils.py:273-275), D = 256 on the
+    160 x 200 map -- clutter_kernel<256> on the matrix cores (K > 8; K = 2560 is the reference's full bank,
+    TrainNeMo.sh:24-25) and clutter_dot_kernel<256> (K = 1).  Full maps against float64 numpy, a band of rows
+    against the C oracle, and a ragged map (13 x 19 pixels: the last tile of 32 pixels is partial)."""
+    from nemo_amd.engine import PoseEngine
+    rng = np.random.default_rng(40 + K)
+    D, h, w, n = 256, 160, 200, 2
+    eng = PoseEngine(200, (h, w), D)
+    feats = syn.unit_rows(rng, n * h * w, D).reshape(n, h, w, D)
+    cb = syn.unit_rows(rng, K, D)
+    out = eng.clutter_score(_dev(feats), _dev(cb)).cpu().numpy()
+    ref = (feats.reshape(-1, D).astype(np.float64) @ cb.astype(np.float64).T).max(axis=1).reshape(n, h, w)
+    assert np.abs(out - ref).max() <= 2e-6
+    rows = 20 if K > 64 else h                                      # the scalar oracle does 1.3 GFLOP per 20 rows at K = 2560
+    cfg = oracle.make_cfg(200, rows, w, D, eng.ndc_scale)
+    for i in range(n):
+        assert np.abs(out[i, :rows] - oracle.clutter_score(cfg, feats[i, :rows], cb)).max() <= 2e-6
+    small = PoseEngine(24, (13, 19), D)
+    f2 = syn.unit_rows(rng, 3 * 13 * 19, D).reshape(3, 13, 19, D)
+    o2 = small.clutter_score(_dev(f2), _dev(cb)).cpu().numpy()
+    c2 = oracle.make_cfg(24, 13, 19, D, small.ndc_scale)
+    for i in range(3):
+        assert np.abs(o2[i] - oracle.clutter_score(c2, f2[i], cb)).max() <= 2e-6
+
+
 @pytest.mark.parametrize('persp,clutter', [(False, True), (True, True), (False, False)])
 def test_score_fwd_bwd(oracle, persp, clutter):
     sc = make_scene(n_img=3, perspective_correct=persp, clutter=clutter)
@@ -702,6 +729,125 @@ def test_multicuboid_argmin_over_meshes():
     assert ((win % 3) == np.arange(6) // 2).sum() >= 5            # the generating subtype explains its image best
 
 
+def test_multicuboid_full_size_vs_oracle(oracle):
+    """BASELINE config 3 at its image size: one class (car) at 640x800, 4 CAD subtypes with their own cuboids
+    and banks, 4 images, every image solved with every subtype (16 jobs: grid init + 300 steps), best final
+    loss wins.  Per job: same grid-search start as the oracle's solve_batch with that subtype's mesh, loss and
+    gradient teacher-forced along the GPU's own trajectory; free-running final pose and loss against the
+    oracle's solve for the jobs whose mesh is the one the image was made with (a wrong subtype's loss surface
+    is rough and the two free-running solves part at the first edge-pixel flip: teacher-forced parity only);
+    per image: the same winning subtype."""
+    import threading
+    from nemo_amd.pose_solver import BatchPoseSolver, SolverConfig, argmin_over_meshes
+    rng = np.random.default_rng(33)
+    n_sub, n_img = 4, 4
+    s = BatchPoseSolver(SolverConfig())
+    eng = s.engine
+    d = syn.DISTANCE_RENDER['car']
+    subs = []
+    for k, jit in enumerate(((1.0, 1.0, 1.0), (0.75, 1.0, 1.2), (1.25, 0.85, 0.9), (0.9, 1.2, 0.8))):
+        v, f = syn.class_mesh('car', 1000, jitter=np.asarray(jit))
+        bank = syn.unit_rows(rng, len(v), 128)
+        s.add_mesh(v, f, bank, d)
+        subs.append((np.stack([v[:, 0], v[:, 2], -v[:, 1]], 1).astype(np.float32), f.astype(np.int32), bank))
+    cfg = oracle.make_cfg(eng.S, eng.h, eng.w, eng.D, eng.ndc_scale)
+    true_sub = np.arange(n_img) % n_sub
+    az, el, th, ds = syn.random_gt_poses(rng, n_img, d)
+    feats = []
+    for i in range(n_img):
+        vp, f, bank = subs[true_sub[i]]
+        R, T = oracle.campos_to_R_T(syn.spherical_to_campos(ds[i], el[i], az[i]), th[i])
+        p2f, bary, _ = oracle.rasterize(cfg, oracle.project(vp, R, T, eng.ndc_scale), f)
+        rend = oracle.interpolate(cfg, p2f, bary, f, bank)
+        feats.append(syn.make_feature_maps(rng, rend[None], (p2f >= 0)[None], 0.5)[0])
+    feats = np.stack(feats)
+    cvec = syn.unit_rows(rng, 1, 128)
+    img = torch.arange(n_img, dtype=torch.int32, device='cuda').repeat_interleave(n_sub).contiguous()
+    mesh = torch.arange(n_sub, dtype=torch.int32, device='cuda').repeat(n_img).contiguous()
+    res = s.solve_all(_dev(feats), _dev(cvec), mesh, img_idx=img, want_trace=True)
+    win = argmin_over_meshes(res, n_img, img).cpu().numpy()
+    pose = torch.cat([res.campos, res.theta[:, None]], 1).cpu().numpy()
+    loss, best, trace = res.loss.cpu().numpy(), res.init_index.cpu().numpy(), res.trace.cpu().numpy()
+    gC, gT = s.grid_C.cpu().numpy(), s.grid_theta.cpu().numpy()
+    clus = [oracle.clutter_score(cfg, feats[i], cvec) for i in range(n_img)]
+    for j in range(n_img * n_sub):
+        vp, f, bank = subs[j % n_sub]
+        for t in (0, 120, 299):
+            e = oracle.evaluate(cfg, vp, f, bank, feats[j // n_sub], clus[j // n_sub], trace[j, t, 0:3], trace[j, t, 3])
+            assert abs(trace[j, t, 4] - e['loss']) <= REL * abs(e['loss'])
+            assert _relerr(trace[j, t, 5:9], np.r_[e['gC'], e['gtheta']]) <= REL
+    tab = syn.adam_table(300)
+    out = [None] * (n_img * n_sub)
+
+    def work(j):
+        vp, f, bank = subs[j % n_sub]
+        out[j] = oracle.solve_batch(cfg, vp, f, bank, feats[j // n_sub:j // n_sub + 1], cvec[0], gC[j % n_sub], gT[j % n_sub],
+                                    tab, nthreads=1)
+
+    ths = [threading.Thread(target=work, args=(j,)) for j in range(len(out))]
+    [t.start() for t in ths]; [t.join() for t in ths]
+    o_loss = np.array([o[2][0] for o in out])
+    errs = []
+    for j, (oC, oth, ol, oi) in enumerate(out):
+        assert int(oi[0]) == int(best[j])                                       # same grid-search start
+        errs.append(np.degrees(pose_error(_decode(pose[j, :3], pose[j, 3]), _decode(oC[0], oth[0]))))
+    errs = np.asarray(errs)
+    close = errs <= 0.5
+    own = np.array([i * n_sub + true_sub[i] for i in range(n_img)])             # jobs with the generating subtype
+    assert close[own].all(), errs                                               # north_star: final poses within 0.5 degrees
+    # (with a wrong subtype's mesh the two free-running solves usually part: 6 of 16 stay within 0.5 degrees)
+    assert np.abs(loss - o_loss)[close].max() <= 1e-3                           # free-running: the last Adam steps still move the loss in the 4th digit
+    g_win, o_win = loss.reshape(n_img, n_sub).argmin(1), o_loss.reshape(n_img, n_sub).argmin(1)
+    assert np.array_equal(win - np.arange(n_img) * n_sub, g_win)               # argmin_over_meshes: lowest final loss per image
+    for i in range(n_img):
+        if close[i * n_sub:(i + 1) * n_sub].all():                              # every subtype's solve tracked the oracle's:
+            assert g_win[i] == o_win[i]                                         # then the winners agree as well
+    # the subtype an image was made with explains it best, here and for the oracle
+    assert (g_win == true_sub).sum() >= n_img - 1 and (o_win == true_sub).sum() >= n_img - 1, (g_win, o_win, loss, o_loss)
+
+
+def test_multicuboid_79_meshes_registration_and_prerender():
+    """All 79 MultiCuboid subtype meshes (dataset/kp_list.py:14 mesh_len) in one context at 640x800: every
+    (mesh, grid) pair pre-rendered (the dense maps take 46 GB of the 288 GB), one job per mesh.  Properties:
+    the matrix-core grid search over the stored maps agrees with rendering each pose on the fly (a second
+    context without a store), same first minimum; the solve from there descends and stays finite."""
+    from nemo_amd.pose_solver import BatchPoseSolver, SolverConfig
+    from nemo_amd.workloads import _render_features
+    rng = np.random.default_rng(44)
+    cfg = SolverConfig()
+    s, s2 = BatchPoseSolver(cfg), BatchPoseSolver(cfg)
+    cat_of_mesh = []
+    for c in syn.CATEGORIES:
+        for _ in range(syn.MESH_LEN[c]):
+            v, f = syn.class_mesh(c, 1000, jitter=rng.uniform(0.8, 1.25, 3))
+            bank = syn.unit_rows(rng, len(v), cfg.feat_dim)
+            s.add_mesh(v, f, bank, syn.DISTANCE_RENDER[c])
+            s2.add_mesh(v, f, bank, syn.DISTANCE_RENDER[c])
+            cat_of_mesh.append(c)
+    n = len(cat_of_mesh)
+    assert n == 79 == s.engine.n_meshes
+    gt = np.zeros((n, 4))
+    for i, c in enumerate(cat_of_mesh):
+        az, el, th, ds = syn.random_gt_poses(rng, 1, syn.DISTANCE_RENDER[c])
+        gt[i] = (th[0], el[0], az[0], ds[0])
+    mesh = torch.arange(n, dtype=torch.int32, device='cuda')
+    feats = _render_features(s, mesh, gt, rng, 0.5)
+    clutter = s.clutter_vector(_dev(syn.unit_rows(rng, 64, cfg.feat_dim)))
+    res = s.solve_all(feats, clutter, mesh, want_trace=True)          # prerenders 79 x 144 poses, matrix-core grid search
+    assert s.engine.lib is not None and s._pre_key is not None
+    clu = s.engine.clutter_score(feats, clutter)
+    _, _, b_pre, l_pre = s.engine.grid_search(feats, clu, s.grid_C, s.grid_theta, mesh_idx=mesh, grid_idx=mesh)
+    _, _, b_fly, l_fly = s2.engine.grid_search(feats, clu, s2.grid_C, s2.grid_theta, mesh_idx=mesh, grid_idx=mesh)
+    assert (l_pre - l_fly).abs().max().item() <= 1e-5 and torch.equal(b_pre, b_fly) and torch.equal(b_pre, res.init_index)
+    tr = res.trace.cpu().numpy()
+    assert np.isfinite(tr).all() and tr[:, -1, 4].mean() < tr[:, 0, 4].mean() - 0.005
+    rec = res.packed().cpu().numpy()
+    errs = [pose_error((rec[i, 3], rec[i, 1], rec[i, 2], rec[i, 0]), tuple(gt[i])) for i in range(n)]
+    # random-init vertex features decorrelate within a few pixels, so a grid start 15 degrees off carries little
+    # signal and about a third of the solves stay in a wrong basin; the rest land on the truth
+    assert np.degrees(np.median(errs)) < 1.0 and np.mean(np.asarray(errs) < np.pi / 18) >= 0.5, np.degrees(errs)
+
+
 def test_reference_style_loop_through_module(oracle):
     """The reference's own solve loop (code/MeshPoseSolveAll.py:227-250), written against the drop-in
     MeshInterpolateModule + torch autograd + torch.optim.Adam, tracks the fused solve kernel."""
@@ -743,9 +889,91 @@ def test_reference_style_loop_through_module(oracle):
     assert np.abs(np.r_[C.detach().cpu().numpy()[0], theta.item()] - trace[6, :4]).max() < 5e-3
 
 
-def test_solve_all_runner_from_files(tmp_path):
+def test_module_batched_modes(oracle):
+    """MeshInterpolateModule's two batched modes (lib/MeshUtils.py:218-221): n cameras on one mesh (the reference
+    extends the mesh n times) and one camera per mesh of a mesh list.  Each rendered map is bit-identical to the
+    oracle's rasterize + interpolate at the same (R, T); fragments carry PyTorch3D's packed face ids; gradients
+    reach campos / theta of every camera."""
+    from nemo_amd import mesh_utils as mu
+    a = make_scene('car', n_img=1, seed=61)
+    b = make_scene('bus', n_img=1, seed=62, number_vertices=500)
+    S, h, w = a.geo.S, a.geo.h, a.geo.w
+
+    def rasterizer():
+        return mu.MeshRasterizer(cameras=mu.OpenGLPerspectiveCameras(device='cuda:0', fov=12.0),
+                                 raster_settings=mu.RasterizationSettings(image_size=S, blur_radius=0.0, faces_per_pixel=1, bin_size=0))
+
+    def pascal(sc):
+        return torch.as_tensor(np.stack([sc.verts[:, 0], -sc.verts[:, 2], sc.verts[:, 1]], 1))
+
+    rng = np.random.default_rng(63)
+    crop = mu.center_crop_fun((h, w), (S, S))
+    # --- n_cam > 1, one mesh
+    one = mu.MeshInterpolateModule(pascal(a), torch.as_tensor(a.faces), torch.as_tensor(a.bank), rasterizer(), post_process=crop).to('cuda')
+    C, th = random_poses(rng, 3, a.distance)
+    Ct, tht = _dev(C).requires_grad_(True), _dev(th).requires_grad_(True)
+    out = one(Ct, tht)
+    assert out.shape == (3, a.D, h, w)
+    R, T = mu.campos_to_R_T(Ct.detach(), tht.detach(), device='cuda')
+    Rn, Tn = R.cpu().numpy(), T.cpu().numpy()
+    for i in range(3):
+        p2f, bary, _ = oracle.rasterize(a.cfg, oracle.project(a.verts, Rn[i], Tn[i], a.cfg.ndc_scale), a.faces)
+        ref = oracle.interpolate(a.cfg, p2f, bary, a.faces, a.bank)
+        assert np.array_equal(out[i].detach().permute(1, 2, 0).cpu().numpy(), ref) and (p2f >= 0).any()
+    fr = one.fragments(R, T)
+    F = len(a.faces)
+    for i in range(3):  # packed ids: batch element i is offset by i * F (meshes.extend(n))
+        ids = fr.pix_to_face[i, ..., 0]
+        assert ((ids == -1) | ((ids >= i * F) & (ids < (i + 1) * F))).all()
+    (out * _dev(a.feats[0]).permute(2, 0, 1)).sum().backward()
+    assert torch.isfinite(Ct.grad).all() and (Ct.grad.abs().sum(1) > 0).all() and (tht.grad != 0).all()
+    # --- one camera per mesh
+    two = mu.MeshInterpolateModule([pascal(a), pascal(b)], [torch.as_tensor(a.faces), torch.as_tensor(b.faces)],
+                                   [torch.as_tensor(a.bank), torch.as_tensor(b.bank)], rasterizer(), post_process=crop).cuda()
+    C2, th2 = random_poses(rng, 2, a.distance)
+    out2 = two(_dev(C2), _dev(th2))
+    R2, T2 = mu.campos_to_R_T(_dev(C2), _dev(th2), device='cuda')
+    R2n, T2n = R2.cpu().numpy(), T2.cpu().numpy()
+    for i, sc in enumerate((a, b)):
+        p2f, bary, _ = oracle.rasterize(sc.cfg, oracle.project(sc.verts, R2n[i], T2n[i], sc.cfg.ndc_scale), sc.faces)
+        ref = oracle.interpolate(sc.cfg, p2f, bary, sc.faces, sc.bank)
+        assert np.array_equal(out2[i].permute(1, 2, 0).cpu().numpy(), ref)
+    ids = two.fragments(R2, T2).pix_to_face[1, ..., 0]
+    assert ((ids == -1) | ((ids >= F) & (ids < F + len(b.faces)))).all() and (ids >= 0).any()
+    with pytest.raises(ValueError):
+        two(_dev(C), _dev(th))                                        # three cameras, two meshes
+    # the module's free functions (lib/MeshUtils.py:83-133) on an extended Meshes + tiled face memory, as the
+    # reference's n_cam > 1 branch calls them (:221): the full S x S render, cropped, is the module's output
+    meshes = mu.Meshes([torch.as_tensor(a.verts)], [torch.as_tensor(a.faces)]).to('cuda')
+    fm = mu.vertex_memory_to_face_memory(_dev(a.bank), _dev(a.faces, torch.int64))
+    full = mu.forward_interpolate(R, T, meshes.extend(3), fm.repeat(3, 1, 1).view(-1, *fm.shape[1:]), rasterizer())
+    assert full.shape == (3, a.D, S, S) and torch.equal(crop(full), out.detach())
+    fr2 = mu.rasterize(R, T, meshes.extend(3), rasterizer())
+    assert torch.equal(crop(fr2.pix_to_face[..., 0]), fr.pix_to_face[..., 0])
+    assert torch.equal(crop(fr2.bary_coords[..., 0, :].permute(0, 3, 1, 2)), fr.bary_coords[..., 0, :].permute(0, 3, 1, 2))
+    # off_set_mesh / deform_verts (:212-213), forward only: offsets of zero change nothing, a rigid shift equals
+    # a module built from the shifted vertices
+    off = mu.MeshInterpolateModule(pascal(a), torch.as_tensor(a.faces), torch.as_tensor(a.bank), rasterizer(), post_process=crop,
+                                   off_set_mesh=True).cuda()
+    V = len(a.verts)
+    assert torch.equal(off(_dev(C), _dev(th), deform_verts=torch.zeros(V, 3, device='cuda')), out.detach())
+    shift = torch.tensor([0.03, -0.02, 0.01], device='cuda').expand(V, 3)
+    moved = mu.MeshInterpolateModule(pascal(a) + torch.tensor([0.03, -0.01, -0.02]), torch.as_tensor(a.faces), torch.as_tensor(a.bank),
+                                     rasterizer(), post_process=crop).cuda()          # (x, y, z) -> (x, z, -y) of the shift
+    assert torch.equal(off(_dev(C), _dev(th), deform_verts=shift), moved(_dev(C), _dev(th)))
+    # mode='nearest' (lib/MeshUtils.py:126-127,136-141): each covered pixel takes its nearest vertex's feature
+    near = one(_dev(C), _dev(th), mode='nearest')
+    p2f, bary, _ = oracle.rasterize(a.cfg, oracle.project(a.verts, Rn[0], Tn[0], a.cfg.ndc_scale), a.faces)
+    onehot = np.where((p2f >= 0)[..., None], np.eye(3, dtype=np.float32)[bary.argmax(-1)], bary)
+    assert np.array_equal(near[0].permute(1, 2, 0).cpu().numpy(), oracle.interpolate(a.cfg, p2f, onehot, a.faces, a.bank))
+
+
+def test_solve_all_runner_from_files(tmp_path, oracle):
     """`python -m nemo_amd.solve_all` (the batched code/MeshPoseSolveAll.py): feature npz + CAD .off files +
-    per-image annotation npz in, per-category error record out, then the CalAccuracy table."""
+    per-image annotation npz in, per-category error record out, then the CalAccuracy table.  The two subtypes
+    carry DIFFERENT clutter banks (the reference reads `clutter_<subtype>` inside its subtype loop, :203-207):
+    every image's clutter map and grid-search start are checked against the oracle run with its own subtype's
+    clutter vector."""
     from nemo_amd import mesh_utils as mu, records, solve_all
     image_hw = (256, 384)
     scs = [make_scene(image_hw=image_hw, n_img=3, seed=21), make_scene(image_hw=image_hw, n_img=2, seed=22,
@@ -758,7 +986,7 @@ def test_solve_all_runner_from_files(tmp_path):
         pascal = np.stack([sc.verts[:, 0], -sc.verts[:, 2], sc.verts[:, 1]], 1)       # undo pre_process_mesh_pascal
         mu.save_off(str(mesh_dir / ('%02d.off' % (k + 1))), pascal, sc.faces)
         mem[st] = sc.bank
-        clu[st] = np.repeat(scs[0].cvec[None], 5, 0)                                   # mean -> the clutter vector
+        clu[st] = syn.unit_rows(np.random.default_rng(70 + k), 5, sc.D)                # a bank of its own per subtype
         names[st] = ['img_%d_%d' % (k, i) for i in range(len(sc.feats))]
         for i, n in enumerate(names[st]):
             feats[n] = np.ascontiguousarray(sc.feats[i].transpose(2, 0, 1))            # [D,h,w] as ExtractFeatures
@@ -775,6 +1003,25 @@ def test_solve_all_runner_from_files(tmp_path):
     assert np.degrees(np.median(te)) < 2.0 and np.mean(te < np.pi / 18) >= 0.8
     rows, text = records.accuracy_table_from_dir(str(tmp_path / 'acc'), categories=['car'])
     assert rows[3, 0] == 5 and 'MedErr' in text
+    # per image against the oracle, each with the clutter vector of ITS subtype: normalize(mean(bank)) (:207)
+    args = solve_all.build_parser().parse_args(['--type_', 'car', '--record_file', rec_path, '--mesh_path', str(mesh_dir),
+                                                '--image_size', '256,384'])
+    with records.FeatureRecord(rec_path) as rec:
+        all_names, mesh_of = solve_all.category_jobs(rec, ['mesh01', 'mesh02'])
+        recs, info = solve_all.solve_shard(args, rec, ['mesh01', 'mesh02'], all_names, mesh_of, 'cuda:0')
+    assert mesh_of == [0, 0, 0, 1, 1] and recs.shape == (5, 10)
+    got_clu, best = info['clu'].cpu().numpy(), info['result'].init_index.cpu().numpy()
+    gC, gth = syn.pose_grid(scs[0].distance)
+    for i, k in enumerate(mesh_of):
+        sc = scs[k]
+        m = clu['mesh%02d' % (k + 1)].mean(0)
+        cvec = (m / np.sqrt((m ** 2).sum())).astype(np.float32)
+        f = sc.feats[i if k == 0 else i - 3]
+        ref_clu = oracle.clutter_score(sc.cfg, f, cvec)
+        assert np.abs(got_clu[i] - ref_clu).max() <= 2e-6
+        bo, _ = oracle.grid_search(sc.cfg, sc.verts, sc.faces, sc.bank, f, ref_clu, gC, gth)
+        assert bo == best[i]
+    assert np.abs(got_clu[0] - oracle.clutter_score(scs[0].cfg, scs[0].feats[0], clu['mesh02'].mean(0))).max() > 1e-3
     # 6-DoF variant through the same runner: final_pred.npz rows (PredUnlabeledDataset.py:344-347)
     pred_path = str(tmp_path / 'final_pred.npz')
     assert solve_all.main(['--type_', 'car', '--record_file', rec_path, '--mesh_path', str(mesh_dir), '--anno_path', '',
@@ -844,6 +1091,17 @@ def test_large_mesh_256d_double_resolution(oracle):
     eng.grid_prerender(dC, dth, [(0, 0)])
     _, _, b1, l1 = eng.grid_search(_dev(sc.feats), _dev(sc.clus), dC, dth)
     assert np.abs(l1[0].cpu().numpy() - lo).max() <= REL * np.abs(lo).max() and int(b1[0]) == bo
+    # config 5 keeps the K-vector clutter bank (max over K, lib/MeshUtils.py:273-275): the occlusion-aware loss and
+    # its gradient with the clutter map of a 64-vector bank from the matrix-core kernel, against the oracle's own
+    cb = syn.unit_rows(rng, 64, 256)
+    cluK = eng.clutter_score(_dev(sc.feats), _dev(cb))
+    cluK_o = oracle.clutter_score(sc.cfg, sc.feats[0], cb)
+    assert np.abs(cluK[0].cpu().numpy() - cluK_o).max() <= 2e-6 and (cluK_o > sc.clus[0]).mean() > 0.9
+    loss, grad, ncov = eng.score_fwd_bwd(_dev(sc.feats), cluK, _dev(C), _dev(th), img_idx=_dev([0, 0], torch.int32))
+    for i in range(2):
+        e = oracle.evaluate(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[0], cluK_o, C[i], th[i])
+        assert abs(loss[i].item() - e['loss']) <= REL * abs(e['loss'])
+        assert _relerr(grad[i].cpu().numpy(), np.r_[e['gC'], e['gtheta']]) <= REL
 
 
 def test_loss_landscape_scans(oracle):
