@@ -1,17 +1,18 @@
 // nemo_hip.hip -- hand-written CDNA4 (gfx950) kernels + C ABI of libnemo_hip.so.
 //
-// One workgroup (512 threads = 8 wave64) owns one job (image, mesh) and runs the
-// whole render-and-compare evaluation out of LDS:
+// One workgroup (1024 threads = 16 wave64, the CU's whole LDS) owns one job (image, mesh) and runs the
+// whole render-and-compare evaluation out of LDS (eval_pose):
 //   camera (look-at, theta)  ->  project vertices into LDS
 //   -> face-parallel rasterisation into a packed 64-bit LDS z-buffer
 //      (key = pz bits << 32 | face id; ds_min_u64 == "nearest fragment, lowest
 //      face index on ties", the exact outcome of PyTorch3D's naive K=1 loop)
-//   -> per-wave compaction of covered pixels
-//   -> fused interpolate + score: 8 lanes per pixel, 16-byte loads of the pixel's
-//      feature row and the face's three vertex-bank rows, three 128-d dot
-//      products reduced with DPP, loss term and dL/d(bary)
-//   -> hand-derived backward to dL/dR, dL/dT (12 scalars, deterministic tree
-//      reduction, no atomics) -> dL/dC, dL/dtheta -> Adam, all inside the kernel.
+//   -> face-major list of the covered pixels (deterministic order)
+//   -> fused interpolate + score: every wave owns a contiguous run of the list; 16 lanes per pixel,
+//      16-byte loads of the pixel's feature row and of the face's three vertex-bank rows (kept in
+//      registers while consecutive entries share them), three 128-d dot products reduced with DPP,
+//      then one lane per pixel for the loss term and dL/d(bary)
+//   -> hand-derived backward to dL/dR, dL/dT (12 scalars, fixed reduction tree, no atomics)
+//      -> dL/dC, dL/dtheta -> Adam, all inside the kernel.
 // The solve kernel loops this 300 times without returning to the host.
 //
 // Build with -ffp-contract=off: coverage is decided by separately rounded fp32
@@ -44,9 +45,9 @@ constexpr int RED_N = 16;      // floats per wave in the reduction scratch
 #endif
 constexpr int CH = NEMO_CHUNK;  // covered pixels per score chunk (multiple of 64)
 constexpr int UST_N = 96;      // floats of workgroup-uniform state kept in LDS
-// uniform-state slots: R[0..8] T[9..11] p[12..15] m[16..19] v[20..23] K[24], chunk counter [25], block totals [32..45],
+// uniform-state slots: R[0..8] T[9..11] p[12..15] m[16..19] v[20..23] K[24], block totals [32..45],
 // camera intermediates of the current iterate [48..82] (kept for the camera backward)
-constexpr int U_R = 0, U_T = 9, U_P = 12, U_M = 16, U_V = 20, U_K = 24, U_CTR = 25, U_TOT = 32, U_CAM = 48;
+constexpr int U_R = 0, U_T = 9, U_P = 12, U_M = 16, U_V = 20, U_K = 24, U_TOT = 32, U_CAM = 48;
 constexpr int U_P6 = 84, U_M6 = 86, U_V6 = 88;  // 6-DoF variant: trans_2d and its Adam moments
 // block totals: [0] loss term, [1..9] dL/dR, [10..12] dL/dT, [13] covered pixels
 constexpr int T_LOSS = 0, T_GR = 1, T_GT = 10, T_NCOV = 13;
@@ -341,15 +342,6 @@ __device__ __forceinline__ float wave_max(float v) {
 // Diagnostic build only (-DNEMO_STAMPS): wave 0 / lane 0 of every workgroup adds the
 // cycles it spent per phase (barrier waits included) into g_stamps; the shipped
 // library contains none of this.
-#ifndef NEMO_SEG
-#define NEMO_SEG 1  // 1: static wave-contiguous score segments, one reduction per wave; 0: dynamic guided chunks
-#endif
-#ifndef NEMO_RABL
-#define NEMO_RABL 0  // rasteriser ablations (diagnostic builds): 1 = no candidate loop, 2 = candidates never accepted
-#endif
-#ifndef NEMO_ABL
-#define NEMO_ABL 0  // diagnostic builds (solve kernel only): 1 = no feature-row loads, 2 = no bank-row loads, 4 = no phase A loop
-#endif
 #ifdef NEMO_STAMPS
 __device__ unsigned long long g_stamps[16];
 __device__ unsigned long long g_wave_busy[16];  // score-loop busy time by wave index
@@ -388,44 +380,8 @@ struct Lds {
   float *ust;            // [UST_N] workgroup-uniform state (camera, Adam)
 };
 
-// Score chunks come in guided sizes: CH entries for the bulk of the face-major list, then CH_MID, then
-// CH_SMALL for the last NW*CH_SMALL entries, so that the waves run out of work within a few pixels of each other.
-// The plan is a function of the list length only (the chunk-order sum stays deterministic).
-struct ChunkPlan {
-  int n_big, n_mid, b_mid, b_small, nchunks;
-};
-__host__ __device__ inline int max_chunks(int cap) { return cap / CH + 2 * NW + 24; }
-#ifndef NEMO_CHUNK_MID
-#define NEMO_CHUNK_MID 64
-#endif
-#ifndef NEMO_CHUNK_SMALL
-#define NEMO_CHUNK_SMALL 32
-#endif
-constexpr int CH_MID = NEMO_CHUNK_MID < CH ? NEMO_CHUNK_MID : CH, CH_SMALL = NEMO_CHUNK_SMALL;
-__device__ __forceinline__ ChunkPlan plan_chunks(int ntot) {
-  ChunkPlan c;
-  const int bulk = max(0, ntot - NW * (CH_SMALL + CH_MID));
-  c.n_big = (bulk + CH - 1) / CH;
-  c.b_mid = c.n_big * CH;
-  const int mid = max(0, ntot - c.b_mid - NW * CH_SMALL);
-  c.n_mid = (mid + CH_MID - 1) / CH_MID;
-  c.b_small = c.b_mid + c.n_mid * CH_MID;
-  c.nchunks = c.n_big + c.n_mid + (max(0, ntot - c.b_small) + CH_SMALL - 1) / CH_SMALL;
-  return c;
-}
-__device__ __forceinline__ void chunk_range(const ChunkPlan &c, int ntot, int id, int &cb, int &cn) {
-  if (id < c.n_big) {
-    cb = id * CH; cn = CH;
-  } else if (id < c.n_big + c.n_mid) {
-    cb = c.b_mid + (id - c.n_big) * CH_MID; cn = CH_MID;
-  } else {
-    cb = c.b_small + (id - c.n_big - c.n_mid) * CH_SMALL; cn = CH_SMALL;
-  }
-  cn = min(cn, ntot - cb);
-}
-
 __host__ __device__ inline size_t zb_region_bytes(int cap) {
-  const size_t a = (size_t)cap * 8, b = (size_t)max_chunks(cap) * 64 + (size_t)NW * CH * (12 + 16);
+  const size_t a = (size_t)cap * 8, b = (size_t)NW * CH * (12 + 16);  // z-buffer, later the score loop's per-wave scratch
   return ((a > b ? a : b) + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t lds_bytes(int cap, int vmax, int fmax, int wmax, int S) {
@@ -500,9 +456,10 @@ __device__ __forceinline__ float block_total(const Lds &L, int i) { return L.ust
 // RAW = true: `feat` holds an upstream gradient dL/d(out) [h][w][D] of the
 // interpolated map and the routine back-propagates it (module path); otherwise
 // `feat` is the image feature map and the loss of MeshPoseSolveAll.py:58-59 is used.
-template <int D, bool PERSP, bool GRAD, bool SCORE, bool RAW = false, bool PRE = false, bool BIG = false>
+template <int D, bool PERSP, bool GRAD, bool SCORE, bool RAW = false, bool PRE = false, bool BIG = false, bool TAIL_SYNC = true>
 __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, const float *__restrict__ feat,
-                          const float *__restrict__ clu, EmitOut emit, bool zb_clean = false) {
+                          const float *__restrict__ clu, EmitOut emit, bool zb_clean = false,
+                          const float *__restrict__ vpre = nullptr) {
 #ifndef NEMO_KIT
 #define NEMO_KIT 2
 #endif
@@ -519,8 +476,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
   const gf32p gclu = as_global(clu);
 
   STAMP_DECL;
-  if (tid < 16) L.ust[U_TOT + tid] = 0.0f;  // ordered before any use by the bounding-box barrier
-  if (tid == 16) *(int *)(L.ust + U_CTR) = 0;
+  if (!SCORE && tid < 16) L.ust[U_TOT + tid] = 0.0f;  // ordered before any use by the bounding-box barrier
   // ---- 1. project vertices (MeshRasterizer.transform; order fixed in DESIGN.md)
   float umin = 3.0e38f, umax = -3.0e38f, tmin = 3.0e38f, tmax = -3.0e38f;
   {
@@ -528,8 +484,12 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
     const float m00 = R[0] * s, m10 = R[3] * s, m20 = R[6] * s, m30 = T[0] * s;
     const float m01 = R[1] * s, m11 = R[4] * s, m21 = R[7] * s, m31 = T[1] * s;
     const float r02 = R[2], r12 = R[5], r22 = R[8], t2 = T[2];
-    for (int v = tid; v < V; v += NT) {
-      const float x = gverts[3 * v], y = gverts[3 * v + 1], z = gverts[3 * v + 2];
+    int slot = 0;
+    for (int v = tid; v < V; v += NT, ++slot) {
+      // vpre: the caller loaded this thread's first two vertices ahead of time (solve kernel: under the Adam section)
+      const bool pre = vpre != nullptr && slot < 2;
+      const float x = pre ? vpre[3 * slot] : gverts[3 * v], y = pre ? vpre[3 * slot + 1] : gverts[3 * v + 1],
+                  z = pre ? vpre[3 * slot + 2] : gverts[3 * v + 2];
       const float xc = ((x * m00 + y * m10) + z * m20) + m30;
       const float yc = ((x * m01 + y * m11) + z * m21) + m31;
       const float zv = ((x * r02 + y * r12) + z * r22) + t2;
@@ -590,7 +550,8 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
 #ifdef NEMO_STAMPS
   unsigned long long st_score0 = 0;
 #endif
-  auto consume = [&](const int ntot, const int ebase) {
+  float tot = 0.0f;  // wave 0, lane i < 13: running total i of the evaluation (T_LOSS, T_GR.., T_GT..)
+  auto consume = [&](const int ntot, const int ebase, const bool last) {
     if (!SCORE) {
       // pre-render: keep the list itself; standalone rasterizer: emit pix_to_face / bary / zbuf
       if (emit.list_out)
@@ -624,33 +585,18 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       //  phase B (one lane per pixel): barycentrics, object score, loss term and the
       //    hand-derived backward to dL/dR, dL/dT accumulators.
       // Both phases are wave-local (LDS operations of one wave complete in order), so
-      // there is no workgroup barrier inside this loop.
-      // Chunks are handed out dynamically (LDS counter) so that no wave idles at the band barrier;
-      // every chunk leaves its 14 partial sums in LDS (the z-buffer is dead by now and hosts them)
-      // and they are added up in chunk order afterwards, so the totals do not depend on which
-      // wave ran which chunk.
+      // there is no workgroup barrier inside this loop.  A wave keeps its 13 sums in registers over
+      // all its chunks, reduces them across lanes once (fixed DPP tree) and leaves them in L.red; the
+      // split of the list over the waves is a function of its length only, so the totals are
+      // reproducible bit for bit.
       constexpr int GPW = 64 / LPP;
       constexpr int NP = GRAD ? 13 : 1;  // partials per chunk: loss term, dL/dR (9), dL/dT (3)
       const int gl = lane & (LPP - 1), grp = lane / LPP;
 #ifdef NEMO_STAMPS
       st_score0 = __builtin_amdgcn_s_memrealtime();
 #endif
-      const ChunkPlan cp = plan_chunks(ntot);
-      const int nchunks = cp.nchunks;
-      float *part = (float *)L.zb;                                  // [nchunks][16]
-      uint4 *rec = (uint4 *)(part + (size_t)max_chunks(P.cap) * 16) + wave * CH;               // [NW][CH]
-      float *gbuf = (float *)((uint4 *)(part + (size_t)max_chunks(P.cap) * 16) + NW * CH) + wave * (CH * 3);  // [NW][CH*3]
-      int *ctr = (int *)(L.ust + U_CTR);
-#ifdef NEMO_STATIC_CHUNKS
-      int static_next = wave;  // diagnostic build: round-robin static chunk assignment
-      auto grab = [&]() { const int v = static_next; static_next += NW; (void)ctr; return v; };
-#else
-      auto grab = [&]() {
-        int v = 0;
-        if (lane == 0) v = atomicAdd(ctr, 1);
-        return __builtin_amdgcn_readfirstlane(v);
-      };
-#endif
+      uint4 *rec = (uint4 *)L.zb + wave * CH;                               // [NW][CH]   (the z-buffer is dead by now
+      float *gbuf = (float *)((uint4 *)L.zb + NW * CH) + wave * (CH * 3);   // [NW][CH*3]  and hosts the wave-private scratch)
       // rows are addressed as uniform base + 32-bit byte offset (feature window and bank are < 4 GiB)
       typedef const __attribute__((address_space(1))) char *gbytep;
       const gbytep fbytes = (gbytep)gfeat, bbytes = (gbytep)bank;
@@ -660,13 +606,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
         const int per_ = (cn_ + GPW - 1) / GPW;
         return (L.list[cb_ + min(grp * per_, cn_ - 1)] & 0xffffu) * (uint32_t)(D * 4) + gl16;
       };
-      auto first_off = [&](int c) {
-        int cb_, cn_;
-        chunk_range(cp, ntot, c, cb_, cn_);
-        return first_off_at(cb_, cn_);
-      };
       f4 xa[KIT], xb[KIT];  // ping-pong: current / next feature-row fragments
-#if NEMO_SEG
       // Static split: wave w owns the contiguous entries [ntot w / NW, ntot (w + 1) / NW) and walks them in
       // chunks of CH; its 13 sums stay in registers across chunks and are reduced across lanes once.
       const int seg_b = (ntot * wave) / NW, seg_e = (ntot * (wave + 1)) / NW;
@@ -674,7 +614,6 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       float GR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       float GT[3] = {0.f, 0.f, 0.f};
       int cb = seg_b;
-      (void)first_off; (void)grab; (void)nchunks;
       if (cb < seg_e) {
         const gf4p Fp = (gf4p)(fbytes + first_off_at(cb, min(CH, seg_e - cb)));
 #pragma unroll
@@ -683,17 +622,6 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       while (cb < seg_e) {
         const int cn = min(CH, seg_e - cb);
         const int cb_next = cb + CH;
-#else
-      int ccur = grab(), cnxt = grab();
-      if (ccur < nchunks) {
-        const gf4p Fp = (gf4p)(fbytes + first_off(ccur));
-#pragma unroll
-        for (int k = 0; k < KIT; ++k) xa[k] = __builtin_nontemporal_load(Fp + LPP * k);
-      }
-      while (ccur < nchunks) {
-        int cb, cn;
-        chunk_range(cp, ntot, ccur, cb, cn);
-#endif
         const int per = (cn + GPW - 1) / GPW;  // entries per lane group in this chunk
         // ---------------- records (one lane per entry): everything phase A needs to know about an entry
         // -- feature-row byte offset and the three bank rows -- is worked out once here, 64 entries per
@@ -720,11 +648,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
           // first feature row of this group in the wave's next chunk (or a harmless reload at the very end)
           const int e0 = grp * per;
           uint4 R0 = rec[min(e0, cn - 1)], R1 = rec[min(e0 + 1, cn - 1)];  // records run two entries ahead
-#if NEMO_SEG
           const uint32_t off_next_chunk = cb_next < seg_e ? first_off_at(cb_next, min(CH, seg_e - cb_next)) : R0.x + gl16;
-#else
-          const uint32_t off_next_chunk = cnxt < nchunks ? first_off(cnxt) : R0.x + gl16;
-#endif
           int i0 = -1, i1 = -1, i2 = -1;
           f4 y0[KIT], y1[KIT], y2[KIT];
 #pragma unroll
@@ -738,19 +662,19 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
               i0 = n0;
               const gf4p B = (gf4p)(bbytes + ((uint32_t)n0 * (uint32_t)(D * 4) + gl16));
 #pragma unroll
-              for (int k = 0; k < KIT; ++k) y0[k] = (GRAD && (NEMO_ABL & 2)) ? f4{(float)n0, 1.f, 2.f, 3.f} : (GRAD && (NEMO_ABL & 16)) ? ((const f4 *)L.list)[((n0 & 31) * (D / 4) + gl + LPP * k) & 2047] : B[LPP * k];
+              for (int k = 0; k < KIT; ++k) y0[k] = B[LPP * k];
             }
             if (n1 != i1) {
               i1 = n1;
               const gf4p B = (gf4p)(bbytes + ((uint32_t)n1 * (uint32_t)(D * 4) + gl16));
 #pragma unroll
-              for (int k = 0; k < KIT; ++k) y1[k] = (GRAD && (NEMO_ABL & 2)) ? f4{(float)n1, 1.f, 2.f, 3.f} : (GRAD && (NEMO_ABL & 16)) ? ((const f4 *)L.list)[((n1 & 31) * (D / 4) + gl + LPP * k) & 2047] : B[LPP * k];
+              for (int k = 0; k < KIT; ++k) y1[k] = B[LPP * k];
             }
             if (n2 != i2) {
               i2 = n2;
               const gf4p B = (gf4p)(bbytes + ((uint32_t)n2 * (uint32_t)(D * 4) + gl16));
 #pragma unroll
-              for (int k = 0; k < KIT; ++k) y2[k] = (GRAD && (NEMO_ABL & 2)) ? f4{(float)n2, 1.f, 2.f, 3.f} : (GRAD && (NEMO_ABL & 16)) ? ((const f4 *)L.list)[((n2 & 31) * (D / 4) + gl + LPP * k) & 2047] : B[LPP * k];
+              for (int k = 0; k < KIT; ++k) y2[k] = B[LPP * k];
             }
             // ... 2nd: the next entry's feature row, which stays in flight (vmcnt is in order)
             {
@@ -758,7 +682,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
               const gf4p Fp = (gf4p)(fbytes + offn);
 #pragma unroll
               for (int k = 0; k < KIT; ++k)
-                xnext[k] = (GRAD && (NEMO_ABL & 1)) ? f4{(float)offn, 1.f, 2.f, 3.f} : __builtin_nontemporal_load(Fp + LPP * k);
+                xnext[k] = __builtin_nontemporal_load(Fp + LPP * k);
             }
             f4 A0 = xc[0] * y0[0], A1 = xc[0] * y1[0], A2 = xc[0] * y2[0];
 #pragma unroll
@@ -784,7 +708,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
             }
             R0 = R1; R1 = R2;
           };
-          int j = (GRAD && (NEMO_ABL & 4)) ? per : 0;
+          int j = 0;
           for (; j + 1 < per; j += 2) {
             body(j, xa, xb);
             body(j + 1, xb, xa);
@@ -797,11 +721,6 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
         }
         STAMP(8);
         // ---------------- phase B: this lane's pixels -> its 13 contributions
-#if !NEMO_SEG
-        float pl = 0.f;
-        float GR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        float GT[3] = {0.f, 0.f, 0.f};
-#endif
 #pragma unroll
         for (int u = 0; u < CH / 64; ++u)
         if (u * 64 + lane < cn) {
@@ -885,34 +804,23 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
             }
           }
         }
-#if NEMO_SEG
         STAMP(9);
         cb = cb_next;
       }
-      const int pslot = wave;  // the wave's partials (fixed DPP tree), written by one lane
-#else
-        const int pslot = ccur;  // chunk partials (fixed DPP tree), written by one lane
-#endif
-        {
-          float pv[13];
-          pv[0] = wave_sum_dpp(pl);
-          if (GRAD) {
+      {  // the wave's partials (fixed DPP tree), left in L.red by one lane
+        float pv[13];
+        pv[0] = wave_sum_dpp(pl);
+        if (GRAD) {
 #pragma unroll
-            for (int i = 0; i < 9; ++i) pv[1 + i] = wave_sum_dpp(GR[i]);
+          for (int i = 0; i < 9; ++i) pv[1 + i] = wave_sum_dpp(GR[i]);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) pv[10 + i] = wave_sum_dpp(GT[i]);
-          }
-          if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < NP; ++i) part[pslot * 16 + i] = pv[i];
-          }
+          for (int i = 0; i < 3; ++i) pv[10 + i] = wave_sum_dpp(GT[i]);
         }
-#if !NEMO_SEG
-        STAMP(9);
-        ccur = cnxt;
-        cnxt = grab();
+        if (lane == 0) {
+#pragma unroll
+          for (int i = 0; i < NP; ++i) L.red[wave * RED_N + i] = pv[i];
+        }
       }
-#endif
     }
     STAMP(4);
 #ifdef NEMO_STAMPS
@@ -927,18 +835,17 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
     }
 #endif
     if (SCORE) {
-      // the waves' partials -> running totals, in wave order, one lane per total (wave 0 owns U_TOT)
+      // the waves' partials -> running totals, in wave order: lane i of wave 0 keeps total i in a register
       constexpr int NPB = GRAD ? 13 : 1;
       if (wave == 0 && lane < NPB) {
-        const float *part = (const float *)L.zb;
-        const int nchunks = NEMO_SEG ? NW : plan_chunks(ntot).nchunks;
-        float t = L.ust[U_TOT + lane];
-        for (int c = 0; c < nchunks; ++c) t += part[c * 16 + lane];
-        L.ust[U_TOT + lane] = t;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) tot += L.red[k * RED_N + lane];
       }
-      if (tid == 0) *(int *)(L.ust + U_CTR) = 0;
+      // After the LAST band nothing of the band's LDS is reused before the caller's next barrier, and the totals
+      // live in wave 0's registers: no second barrier.
+      if (last) return;
     }
-    __syncthreads();  // band's z-buffer / lists are reused by the next band
+    __syncthreads();  // band's z-buffer / lists / L.red are reused by the next band
     STAMP(5);
   };
 
@@ -951,7 +858,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       for (int i = tid; i < ntot; i += NT) L.list[i] = emit.pre_list[pb + i];
       ncov += (tid == 0) ? ntot : 0;
       __syncthreads();
-      consume(ntot, ebase);
+      consume(ntot, ebase, pb + P.cap >= emit.pre_cnt);
       ebase += ntot;
     }
   } else if (!empty_box) {
@@ -1009,7 +916,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
             int ha_lo = 0x7fff, ha_hi = -1, hb_lo = 0x7fff, hb_hi = -1;
             u64 fmask = 0;
             u64 *zrow = L.zb + ((b - bb) * bw - a_lo);
-            for (int c = 0; c < ((NEMO_RABL & 1) ? 0 : ncand); ++c) {
+            for (int c = 0; c < ncand; ++c) {
               const float px = L.ndc[a];
               const float e0 = (px - v[3]) * dy0 - r0;
               const float e1 = (px - v[6]) * dy1 - r1;
@@ -1134,28 +1041,38 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       ncov += (tid == 0) ? ntot : 0;
       __syncthreads();
       STAMP(3);
-      consume(ntot, ebase);
+      consume(ntot, ebase, bb + rows_per_band > b_hi);
       ebase += ntot;
     }
   }
 
-  // ---- 4. totals are already in L.ust[U_TOT..] (the waves' partials added in wave order by wave 0)
-  if (tid == 0) {
-    L.ust[U_TOT + T_NCOV] = (float)ncov;
-    if (GRAD) {  // dL/dR = R * sum((view - T)^T q)
-      const float *R = L.ust + U_R;
-      float W[9], G[9];
+  // ---- 4. totals -> L.ust[U_TOT..]: lane i of wave 0 holds total i; thread 0 collects them (readlane), rotates the
+  // gradient (dL/dR = R * sum((view - T)^T q)) and publishes all 14.  TAIL_SYNC = false (solve kernel): no closing
+  // barrier -- thread 0 itself goes on to the camera backward and Adam, the caller's own barrier publishes.
+  if (SCORE) {
+    if (wave == 0) {
+      float tv[13];
 #pragma unroll
-      for (int i = 0; i < 9; ++i) W[i] = L.ust[U_TOT + T_GR + i];
+      for (int i = 0; i < 13; ++i) tv[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), i));
+      if (tid == 0) {
+        L.ust[U_TOT + T_LOSS] = tv[0];
+        L.ust[U_TOT + T_NCOV] = (float)ncov;
+        if (GRAD) {
+          const float *R = L.ust + U_R;
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
+          for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) G[3 * i + j] = (R[3 * i] * W[j] + R[3 * i + 1] * W[3 + j]) + R[3 * i + 2] * W[6 + j];
+            for (int j = 0; j < 3; ++j)
+              L.ust[U_TOT + T_GR + 3 * i + j] = (R[3 * i] * tv[1 + j] + R[3 * i + 1] * tv[4 + j]) + R[3 * i + 2] * tv[7 + j];
 #pragma unroll
-      for (int i = 0; i < 9; ++i) L.ust[U_TOT + T_GR + i] = G[i];
+          for (int i = 0; i < 3; ++i) L.ust[U_TOT + T_GT + i] = tv[10 + i];
+        }
+      }
     }
+  } else if (tid == 0) {
+    L.ust[U_TOT + T_NCOV] = (float)ncov;
   }
-  __syncthreads();
+  if (TAIL_SYNC) __syncthreads();
   STAMP(6);
 }
 
@@ -1920,8 +1837,22 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
   // The z-buffer of the next step is cleared while thread 0 runs the serial camera / Adam section.
   for (int i = threadIdx.x; i < P.cap; i += NT) L.zb[i] = ~0ull;
   __syncthreads();
+  // This thread's first two vertices are fetched (L2) while thread 0 runs the serial section, not at the top of the step.
+  float vreg[6];
+  auto fetch_verts = [&]() {
+    const gf32p gv = as_global(M.verts);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int v = min((int)threadIdx.x + k * NT, M.V - 1);
+      vreg[3 * k] = gv[3 * v]; vreg[3 * k + 1] = gv[3 * v + 1]; vreg[3 * k + 2] = gv[3 * v + 2];
+    }
+  };
+  fetch_verts();
   for (int t = 0; t < steps; ++t) {
-    eval_pose<D, PERSP, true, true, false, false, BIG>(P, L, M, f, c, none, true);
+    // no closing barrier inside: thread 0 leaves eval_pose with the totals and goes straight on to Adam, the other
+    // waves clear the z-buffer meanwhile (the score loop's scratch in that region is dead behind the band barrier)
+    eval_pose<D, PERSP, true, true, false, false, BIG, false>(P, L, M, f, c, none, true, vreg);
+    fetch_verts();
     for (int i = threadIdx.x; i < P.cap; i += NT) L.zb[i] = ~0ull;
 #ifdef NEMO_STAMPS
     const unsigned long long st_lead = (threadIdx.x == 0) ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -2183,7 +2114,12 @@ static int plan_lds(nemo_ctx *ctx) {
   };
   long cap = cap_for((long)LDS_BUDGET - (long)vmax * 16 - (long)fmax * FACE_BYTES - misc);
   int big = 0;
-  if (cap < c.win_w || cap < (hw < 2048 ? hw : 2048)) {
+#ifdef NEMO_FORCE_BIG
+  const bool force_big = true;
+#else
+  const bool force_big = false;
+#endif
+  if (force_big || cap < c.win_w || cap < (hw < 2048 ? hw : 2048)) {
     // the mesh tables would leave (almost) no z-buffer: keep them in global scratch instead (BIG kernels)
     big = 1;
     cap = cap_for((long)LDS_BUDGET - misc);

@@ -18,9 +18,11 @@ ap.add_argument('--steps', type=int, default=60)
 ap.add_argument('--reps', type=int, default=2)
 ap.add_argument('--grid', action='store_true', help='also time the grid search')
 ap.add_argument('--sort', action='store_true', help='order the jobs by descending coverage at the initial pose (longest first)')
+ap.add_argument('--image-size', default='640,800', help='H,W of the synthetic images (feature maps are 1/8 of it)')
 ap.add_argument('--lr0', action='store_true', help='zero learning rate: every step re-evaluates the initial pose (fixed work for ablations)')
 args = ap.parse_args()
-wl = twelve_class_workload(args.images, seed=1000, cfg=SolverConfig(total_epochs=args.steps, **({'lr': 0.0} if args.lr0 else {})))
+wl = twelve_class_workload(args.images, seed=1000, cfg=SolverConfig(total_epochs=args.steps, image_size=tuple(int(v) for v in args.image_size.split(',')),
+                                                                   **({'lr': 0.0} if args.lr0 else {})))
 s, eng = wl.solver, wl.solver.engine
 clu = eng.clutter_score(wl.feats, wl.clutter)
 C0, th0, _, _ = eng.grid_search(wl.feats, clu, s.grid_C, s.grid_theta, mesh_idx=wl.mesh_idx, grid_idx=wl.mesh_idx)
