@@ -154,7 +154,7 @@ def accuracy_rows(errors_by_category: Dict[str, np.ndarray], categories: Iterabl
     """code/CalAccuracy.py:15-24: rows = pi/6 accuracy %, pi/18 accuracy %, median error in degrees, count;
     one column per category plus the image-weighted mean as the last column."""
     cats = list(categories)
-    out = np.zeros((4, len(cats) + 1), dtype=np.float64)
+    out = np.zeros((4, len(cats) + 1), dtype=np.float32)  # float32 like the reference's table (:14): the printed digits follow it
     for i, c in enumerate(cats):
         e = np.asarray(errors_by_category[c], dtype=np.float64)
         out[0, i] = float(np.mean(e < np.pi / 6)) * 100

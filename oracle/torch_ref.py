@@ -2,7 +2,8 @@
 torch-CPU ops so that torch.autograd differentiates it.
 
 TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (PyTorch3D is not runnable here):
-coverage (pix_to_face) is taken from the C oracle's naive rasterizer; everything
+coverage (pix_to_face) is an input -- the tests take it from oracle/raster_np.py, the array
+rasterizer written independently of the C oracle, after checking the two agree; everything
 differentiable -- look-at, rotation_theta (MeshUtils.py:57-80),
 T = -R^T C (:104-111), the composed view/projection transform (P3), barycentrics
 (P4), perspective correction, interpolate_face_attributes (P6), crop, object

@@ -47,6 +47,32 @@ def metric_vectors():
              matrices=mats, pair_errors=np.asarray(errs))
 
 
+def accuracy_table():
+    """accuracy_errors.npz + accuracy_table.txt -- PINNED BY THE REFERENCE: seeded per-category rotation errors
+    (plain float arrays: data, written here) and the text the reference's own code/CalAccuracy.py prints for
+    them, captured by RUNNING that script (numpy only) on records holding exactly those arrays."""
+    import subprocess
+    import tempfile
+    cats = ['aeroplane', 'bicycle', 'boat', 'bottle', 'bus', 'car', 'chair', 'diningtable', 'motorbike', 'sofa',
+            'train', 'tvmonitor']
+    rng = np.random.default_rng(21)
+    errs = {}
+    for k, c in enumerate(cats):
+        n = int(rng.integers(40, 400))
+        e = np.abs(rng.normal(0, 0.05 + 0.04 * k, n))
+        e[rng.random(n) < 0.08] = rng.uniform(0.5, np.pi, int((rng.random(n) < 0.08).sum() or 1))[0]   # gross failures
+        e[::17] = np.pi / 2                                                                          # NaN -> pi/2 solves (:262-263)
+        errs[c] = e.astype(np.float64)
+    with tempfile.TemporaryDirectory() as d:
+        for c in cats:
+            np.savez(os.path.join(d, c + '_occ1.npz'), total_error=errs[c])
+        out = subprocess.run([sys.executable, '/root/reference/code/CalAccuracy.py', '--load_accuracy', d, '--data_pendix', '_occ1'],
+                             check=True, capture_output=True, text=True).stdout
+    np.savez_compressed(os.path.join(HERE, 'accuracy_errors.npz'), **errs)
+    with open(os.path.join(HERE, 'accuracy_table.txt'), 'w') as f:
+        f.write(out)
+
+
 def path_small():
     from nemo_amd import synthetic as syn
     from oracle import oracle as orc
@@ -76,7 +102,12 @@ def path_small():
 
 
 if __name__ == '__main__':
-    metric_vectors()
-    path_small()
-    for f in ('metric_vectors.npz', 'path_small.npz'):
+    which = sys.argv[1:] or ['metric', 'path', 'accuracy']
+    if 'metric' in which:
+        metric_vectors()
+    if 'path' in which:
+        path_small()
+    if 'accuracy' in which:
+        accuracy_table()
+    for f in ('metric_vectors.npz', 'path_small.npz', 'accuracy_errors.npz', 'accuracy_table.txt'):
         print(f, os.path.getsize(os.path.join(HERE, f)), 'bytes')

@@ -244,3 +244,22 @@ def test_fastdiv_chain_is_correctly_rounded():
             q = fma(fma(-d, q1, n), r, q1)
             bad += int(q != rnd(Fraction(float(n)) / Fraction(float(d))))
     assert bad == 0
+
+
+def test_accuracy_table_matches_reference_stdout(tmp_path):
+    """PINNED BY THE REFERENCE: tests/golden/accuracy_table.txt is the stdout of the reference's own
+    code/CalAccuracy.py, run by tests/golden/make_golden.py on records holding the arrays of
+    tests/golden/accuracy_errors.npz; records.accuracy_table_from_dir prints the same text for the same records."""
+    import os
+    from nemo_amd import records
+    gold = os.path.join(os.path.dirname(__file__), 'golden')
+    with np.load(os.path.join(gold, 'accuracy_errors.npz')) as z:
+        errs = {k: z[k] for k in z.files}
+    assert sorted(errs) == sorted(records.CATEGORIES)
+    for c, e in errs.items():
+        records.save_category_errors(str(tmp_path / (c + '_occ1.npz')), e)
+    rows, text = records.accuracy_table_from_dir(str(tmp_path), '_occ1')
+    with open(os.path.join(gold, 'accuracy_table.txt')) as f:
+        want = f.read()
+    assert text + '\n' == want
+    assert rows[3, -1] == sum(len(e) for e in errs.values())

@@ -73,6 +73,70 @@ def test_raster_invariants(oracle):
         assert np.abs(out[cov] - 1).max() < 1e-4 and np.all(out[~cov] == 0)
 
 
+def _window(sc, a):
+    from oracle import raster_np
+    return np.ascontiguousarray(raster_np.crop(a, sc.cfg.S, sc.cfg.h, sc.cfg.w, sc.cfg.r0, sc.cfg.c0))
+
+
+@pytest.mark.parametrize('persp', [False, True])
+@pytest.mark.parametrize('cate,hw,nv', [('car', (256, 384), 300), ('bottle', (384, 256), 200), ('aeroplane', (640, 800), 1000)])
+def test_two_independent_rasterizers_agree(oracle, cate, hw, nv, persp):
+    """The discrete half of the path has two lineages: the C oracle's per-pixel loop and oracle/raster_np.py
+    (float32 array operations over all pixels x all faces, written from SURVEY 8a row P4, sharing no code with the
+    C file).  pix_to_face, barycentrics and z of the full S x S image agree bit for bit, and so does the crop."""
+    from oracle import raster_np
+    sc = make_scene(cate, hw, nv, n_img=1, perspective_correct=persp)
+    rng = np.random.default_rng(12)
+    C, th = random_poses(rng, 4, sc.distance, spread=0.3)
+    for i in range(4):
+        R, T = oracle.campos_to_R_T(C[i], th[i])
+        scr = oracle.project(sc.verts, R, T, sc.cfg.ndc_scale)
+        pf, bf, zf = oracle.rasterize(sc.cfg, scr, sc.faces, crop=False)
+        p2, b2, z2 = raster_np.rasterize(scr, sc.faces, sc.cfg.S, persp, sc.cfg.k_eps)
+        assert (pf >= 0).sum() > 50
+        assert np.array_equal(pf, p2) and np.array_equal(bf, b2) and np.array_equal(zf, z2)
+        pw, bw, _ = oracle.rasterize(sc.cfg, scr, sc.faces)
+        assert np.array_equal(pw, _window(sc, p2)) and np.array_equal(bw, _window(sc, b2))
+
+
+@pytest.mark.parametrize('persp', [False, True])
+def test_two_independent_rasterizers_agree_on_triangle_soups(oracle, persp):
+    """Same, on the inputs that exercise the decision rules: duplicated faces (ties -> lowest index), repeated
+    vertices and collinear faces (kEps skip), a triangle larger than the view in both windings, interpenetrating
+    slivers, vertices behind the camera (pz < 0)."""
+    from oracle import raster_np
+    S, h, w, D = 48, 32, 48, 128
+    s = syn.ndc_scale(12.0)
+    cfg = oracle.make_cfg(S, h, w, D, s, perspective_correct=persp)
+    ties = 0
+    for seed in range(6):
+        rng = np.random.default_rng(100 + seed)
+        V = 120
+        verts = (rng.uniform(-0.5, 0.5, (V, 3)) * np.array([1.0, 0.6, 1.0])).astype(np.float32)
+        faces = rng.integers(0, V, (260, 3)).astype(np.int32)
+        faces[40:60] = faces[0:20]
+        faces[60:70, 2] = faces[60:70, 0]
+        verts[100:104] = np.array([[-3, -3, 0.2], [3, -3, 0.2], [0, 4, 0.2], [0, 0, -0.3]], np.float32) * (1 + 0.1 * seed)
+        faces[70] = (100, 101, 102)
+        faces[71] = (100, 102, 101)
+        faces[72] = (100, 101, 103)
+        verts[104:107] = verts[10] + np.outer(np.arange(3), [0.1, 0.05, 0.0]).astype(np.float32)
+        faces[73] = (104, 105, 106)
+        C, th = random_poses(rng, 4, 5.0, spread=0.3)
+        C[3] = C[3] * 0.08
+        for i in range(4):
+            R, T = oracle.campos_to_R_T(C[i], th[i])
+            scr = oracle.project(verts, R, T, s)
+            pf, bf, zf = oracle.rasterize(cfg, scr, faces, crop=False)
+            p2, b2, z2 = raster_np.rasterize(scr, faces, S, persp, cfg.k_eps)
+            assert np.array_equal(pf, p2), (seed, i, int((pf != p2).sum()))
+            cov = pf >= 0
+            assert np.array_equal(bf[cov], b2[cov]) and np.array_equal(zf[cov], z2[cov])
+            ties += int(np.isin(pf[cov], np.arange(0, 20)).sum())
+            assert not np.isin(pf[cov], np.arange(40, 60)).any()     # a duplicate never beats the original
+    assert ties > 0
+
+
 @pytest.mark.parametrize('persp,clutter', [(False, True), (True, True), (False, False)])
 def test_backward_vs_autograd_and_finite_differences(oracle, persp, clutter):
     from oracle import torch_ref
@@ -82,9 +146,14 @@ def test_backward_vs_autograd_and_finite_differences(oracle, persp, clutter):
     az, el, t, d = sc.gt[0]
     C[0] = syn.spherical_to_campos(d * 1.02, el + 0.03, az - 0.04); th[0] = t + 0.02
     clu = sc.clus[0] if clutter else None
+    from oracle import raster_np
     for i in range(3):
         e = oracle.evaluate(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[0], clu, C[i], th[i], want_maps=True)
-        a = torch_ref.loss_and_grads(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[0], clu, C[i], th[i], e['pix_to_face'])
+        # coverage for the autograd restatement comes from the independent array rasterizer, not from the C oracle
+        R, T = oracle.campos_to_R_T(C[i], th[i])
+        p2f = _window(sc, raster_np.rasterize(oracle.project(sc.verts, R, T, sc.cfg.ndc_scale), sc.faces, sc.cfg.S, persp, sc.cfg.k_eps)[0])
+        assert np.array_equal(p2f, e['pix_to_face'])
+        a = torch_ref.loss_and_grads(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[0], clu, C[i], th[i], p2f)
         assert abs(e['loss'] - a['loss']) < 1e-6
         ga = np.r_[a['gC'], a['gtheta']]; go = np.r_[e['gC'], e['gtheta']]
         assert np.abs(go - ga).max() <= 1e-4 * np.abs(ga).max()
@@ -92,8 +161,8 @@ def test_backward_vs_autograd_and_finite_differences(oracle, persp, clutter):
         eps = 1e-6
         for k in range(4):
             dp = np.zeros(4); dp[k] = eps
-            lp = torch_ref.loss_and_grads(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[0], clu, C[i] + dp[:3], th[i] + dp[3], e['pix_to_face'])['loss']
-            lm = torch_ref.loss_and_grads(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[0], clu, C[i] - dp[:3], th[i] - dp[3], e['pix_to_face'])['loss']
+            lp = torch_ref.loss_and_grads(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[0], clu, C[i] + dp[:3], th[i] + dp[3], p2f)['loss']
+            lm = torch_ref.loss_and_grads(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[0], clu, C[i] - dp[:3], th[i] - dp[3], p2f)['loss']
             fd = (lp - lm) / (2 * eps)
             assert abs(fd - ga[k]) <= 2e-3 * np.abs(ga).max() + 1e-9
 
