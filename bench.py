@@ -72,6 +72,83 @@ def cpu_baseline(wl, n_sample):
                       f'{dt:.1f} s wall; host has {os.cpu_count()} logical CPUs'}
 
 
+def from_files_leg(n_images, dev, batch):
+    """The file-driven entry (python -m nemo_amd.solve_all = the reference's code/MeshPoseSolveAll.py:173,217-219:
+    feature .npz + CAD .off in, poses out) on a synthetic one-category record of `n_images` car images, written to a
+    memory-backed directory.  Reported separately from `value` (H2D of feature maps reported separately):
+    host read rate of the maps into pinned memory, pinned host -> device rate, and end-to-end solves/s with the next
+    batch read + uploaded under the current batch's solve."""
+    import shutil
+    import tempfile
+    from nemo_amd import mesh_utils as mu, records, solve_all, synthetic as syn
+    from nemo_amd.workloads import twelve_class_workload
+    wl = twelve_class_workload(n_images, seed=77, device=dev, categories=['car'])
+    eng = wl.solver.engine
+    host = wl.feats.permute(0, 3, 1, 2).contiguous().cpu().numpy()      # [n, D, h, w]: the layout ExtractFeatures.py stores
+    base = '/dev/shm' if os.path.isdir('/dev/shm') and shutil.disk_usage('/dev/shm').free > 3 * host.nbytes else None
+    d = tempfile.mkdtemp(prefix='nemo_bench_', dir=base)
+    try:
+        names = ['img_%05d' % i for i in range(n_images)]
+        v, f, bank = (t.cpu().numpy() for t in eng._keep[0])
+        pascal = np.stack([v[:, 0], -v[:, 2], v[:, 1]], 1)              # undo pre_process_mesh_pascal
+        os.makedirs(os.path.join(d, 'cad'))
+        mu.save_off(os.path.join(d, 'cad', '01.off'), pascal, f)
+        rec_path = os.path.join(d, 'car.npz')
+        cbank = syn.unit_rows(np.random.default_rng(5), 64, eng.D)
+        t0 = time.perf_counter()
+        records.write_feature_record(rec_path, {'mesh01': bank}, {'mesh01': cbank}, {'mesh01': names},
+                                     {n: host[i] for i, n in enumerate(names)})
+        t_write = time.perf_counter() - t0
+        nbytes = host.nbytes
+        del host, wl
+        torch.cuda.empty_cache()
+        # (a) host side alone: the maps from the record into pinned memory, up to 16 reader threads
+        with records.FeatureRecord(rec_path) as rec:
+            D, h, w = rec.feature_shape(names[0])
+            stage = torch.empty((min(256, n_images), D, h, w), dtype=torch.float32, pin_memory=True)
+            view = stage.numpy()
+            from concurrent.futures import ThreadPoolExecutor
+            nthr = min(16, os.cpu_count() or 1)
+            fds = [os.open(rec_path, os.O_RDONLY) for _ in range(nthr)]
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(nthr) as pool:
+                list(pool.map(lambda j: rec.read_feature_into(names[j], view[j], fds[j % nthr]), range(stage.shape[0])))
+            t_read = time.perf_counter() - t0
+            [os.close(fd) for fd in fds]
+        read_gbs = stage.numel() * 4 / t_read / 1e9
+        # (b) pinned host -> device alone
+        dst = torch.empty_like(stage, device=dev)
+        dst.copy_(stage, non_blocking=True)
+        torch.cuda.synchronize(dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(3):
+            dst.copy_(stage, non_blocking=True)
+        b.record()
+        torch.cuda.synchronize(dev)
+        h2d_gbs = 3 * stage.numel() * 4 / (a.elapsed_time(b) * 1e-3) / 1e9
+        del dst, stage
+        # (c) end to end through the runner (second run: libraries and the page cache are warm, like a second category)
+        args = solve_all.build_parser().parse_args(['--type_', 'car', '--record_file', rec_path, '--mesh_path',
+                                                    os.path.join(d, 'cad'), '--anno_path', '', '--batch', str(batch),
+                                                    '--image_size', '%d,%d' % (8 * h, 8 * w)])
+        dt = None
+        for _ in range(2):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            _, _, recs = solve_all.solve_category(args, str(dev))
+            dt = time.perf_counter() - t0
+        ok = float(np.isfinite(recs[:, :5]).all(axis=1).mean())
+        return {'images': n_images, 'record_bytes': nbytes, 'solves_per_s': n_images / dt, 'seconds': dt, 'batch': batch,
+                'host_read_gbs': read_gbs, 'h2d_gbs': h2d_gbs, 'finite_fraction': ok, 'record_write_s': t_write,
+                'note': 'python -m nemo_amd.solve_all path on one synthetic category (car): uncompressed feature .npz on '
+                        + ('/dev/shm' if base else 'the temp directory') + ', maps read with pread into pinned memory by up to 16 threads, '
+                        'uploaded on a side stream and transposed to pixel-major on the GPU while the previous batch is solved; '
+                        'includes mesh registration and the grid pre-render of the category; never part of `value`'}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def launch_ranks(n_gpus, argv):
     """`bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py ...`
     as a CHILD (the one-command multi-GPU entry, as the reference's InferenceNeMo.sh:42-50,67-81 is one command).
@@ -107,6 +184,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--images', type=int, default=1024, help='images per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--from-files-images', type=int, default=512, help='images in the file-driven leg (0 = skip it)')
+    ap.add_argument('--from-files-batch', type=int, default=256)
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='process-group backend for N > 1: nccl = RCCL over xGMI (the product path); gloo = rehearsal of the '
                          'multi-rank code on a box with fewer GPUs than ranks (records gathered through host memory)')
@@ -209,6 +288,12 @@ def main():
                          'covered_pixel_steps_per_launch': cov_steps},
             'quality': {'finite_fraction': ok, 'median_err_deg_vs_synthetic_gt': float(np.degrees(np.median(errs)))},
         }
+        if world == 1 and args.from_files_images > 0:
+            del res
+            ff = from_files_leg(args.from_files_images, dev, args.from_files_batch)
+            out['from_files'] = ff
+            out['h2d_gbs'] = ff['h2d_gbs']
+            out['from_files_solves_per_s'] = ff['solves_per_s']
         if world == 1 and not args.no_cpu_baseline:
             n_sample = args.cpu_sample or 3 * min(16, os.cpu_count() or 1)
             out['cpu_baseline'] = cpu_baseline(wl, n_sample)

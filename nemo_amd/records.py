@@ -16,6 +16,9 @@ is not needed by any consumer here (CalAccuracy reads ``total_error`` only).
 from __future__ import annotations
 
 import os
+import struct
+import zipfile
+from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
 from typing import Dict, Iterable, List, Optional, Sequence
 
@@ -54,6 +57,66 @@ class FeatureRecord:
         """[D, h, w] f32, the layout ExtractFeatures.py:166-168 stores."""
         return np.asarray(self._z[name], dtype=np.float32)
 
+    # ---- direct reads: np.savez stores members uncompressed, so a map's bytes sit in the file as they are
+    def _layout(self, name: str):
+        """(byte offset of the array data in the .npz, shape) of a STORED little-endian f32 C-order member, else None
+        (compressed record, other dtype: the caller falls back to the zipfile path)."""
+        if not hasattr(self, '_zinfo'):
+            with zipfile.ZipFile(self.path) as zf:
+                self._zinfo = {i.filename: i for i in zf.infolist()}
+            self._layouts = {}
+        if name in self._layouts:
+            return self._layouts[name]
+        info = self._zinfo.get(name + '.npy')
+        lay = None
+        if info is not None and info.compress_type == zipfile.ZIP_STORED:
+            with open(self.path, 'rb') as fh:
+                fh.seek(info.header_offset)
+                local = fh.read(30)
+                n_name, n_extra = struct.unpack('<HH', local[26:30])
+                start = info.header_offset + 30 + n_name + n_extra
+                fh.seek(start)
+                version = np.lib.format.read_magic(fh)
+                shape, fortran, dtype = (np.lib.format.read_array_header_1_0(fh) if version == (1, 0)
+                                         else np.lib.format.read_array_header_2_0(fh))
+                if dtype == np.dtype('<f4') and not fortran:
+                    lay = (fh.tell(), tuple(shape))
+        self._layouts[name] = lay
+        return lay
+
+    def read_feature_into(self, name: str, dst: np.ndarray, fd: Optional[int] = None) -> None:
+        """Fill `dst` ([D, h, w] f32, C-contiguous; e.g. a view of pinned memory) with the map `name`: a straight
+        pread of the member's bytes when the record is uncompressed (no intermediate copy, no CRC pass), else
+        through the zip reader."""
+        lay = self._layout(name)
+        if lay is None:
+            f = self.feature(name)
+            if f.shape != dst.shape:
+                raise ValueError('feature map %r has shape %s, expected %s' % (name, f.shape, dst.shape))
+            dst[...] = f
+            return
+        off, shape = lay
+        if shape != tuple(dst.shape):
+            raise ValueError('feature map %r has shape %s, expected %s' % (name, shape, tuple(dst.shape)))
+        own = fd is None
+        if own:
+            fd = os.open(self.path, os.O_RDONLY)
+        try:
+            view = memoryview(dst).cast('B')
+            done = 0
+            while done < len(view):
+                n = os.preadv(fd, [view[done:]], off + done)
+                if n <= 0:
+                    raise IOError('short read of %r in %s' % (name, self.path))
+                done += n
+        finally:
+            if own:
+                os.close(fd)
+
+    def feature_shape(self, name: str):
+        lay = self._layout(name)
+        return lay[1] if lay is not None else tuple(self.feature(name).shape)
+
     def close(self):
         self._z.close()
 
@@ -63,26 +126,58 @@ class FeatureRecord:
     def __exit__(self, *a):
         self.close()
 
-    def upload_pixel_major(self, names: Sequence[str], device, chunk: int = 64) -> torch.Tensor:
-        """Features of `names` as ONE [N, h, w, D] f32 device tensor (the kernels' layout): maps are staged
-        [D, h, w] in pinned host memory a chunk at a time and transposed on the GPU, so the host never
-        holds a transposed copy."""
-        first = self.feature(names[0])
-        D, h, w = first.shape
+    def upload_pixel_major(self, names: Sequence[str], device, chunk: int = 64, workers: int = 0,
+                           stats: Optional[dict] = None) -> torch.Tensor:
+        """Features of `names` as ONE [N, h, w, D] f32 device tensor (the kernels' layout).  Double-buffered: while
+        chunk k goes host -> device (pinned memory, asynchronous copy on the CURRENT stream) and is transposed to
+        pixel-major on the GPU, `workers` host threads read chunk k + 1 straight from the file into the other pinned
+        buffer.  The host never holds a transposed copy.  stats (optional dict) receives decode / wait times."""
+        import time
+        if workers <= 0:
+            workers = min(16, os.cpu_count() or 1)  # reader threads (a GPU box gives a job 16 CPUs)
+        D, h, w = self.feature_shape(names[0])
         dev = torch.device(device)
         out = torch.empty((len(names), h, w, D), dtype=torch.float32, device=dev)
         pin = dev.type == 'cuda'
-        stage = torch.empty((min(chunk, len(names)), D, h, w), dtype=torch.float32, pin_memory=pin)
-        for s in range(0, len(names), chunk):
-            part = names[s:s + chunk]
-            for i, n in enumerate(part):
-                f = first if (s == 0 and i == 0) else self.feature(n)
-                if f.shape != (D, h, w):
-                    raise ValueError('feature map %r has shape %s, expected %s' % (n, f.shape, (D, h, w)))
-                stage[i].copy_(torch.from_numpy(f))
-            out[s:s + len(part)] = stage[:len(part)].to(dev, non_blocking=pin).permute(0, 2, 3, 1)
-            if pin:
-                torch.cuda.current_stream(dev).synchronize()  # the stage buffer is reused by the next chunk
+        n_stage = min(chunk, len(names))
+        stages = [torch.empty((n_stage, D, h, w), dtype=torch.float32, pin_memory=pin) for _ in range(2 if len(names) > chunk else 1)]
+        views = [st.numpy() for st in stages]
+        free_ev = [None] * len(stages)  # the copy out of a stage buffer must finish before it is refilled
+        fds = [os.open(self.path, os.O_RDONLY) for _ in range(max(1, workers))]
+        t_decode = t_wait = 0.0
+
+        def fill(k, part):
+            def one(j):
+                self.read_feature_into(part[j], views[k][j], fds[j % len(fds)])
+            if workers > 1 and len(part) > 1:
+                list(pool.map(one, range(len(part))))
+            else:
+                for j in range(len(part)):
+                    one(j)
+
+        pool = ThreadPoolExecutor(max_workers=max(1, workers))
+        try:
+            for ci, s in enumerate(range(0, len(names), chunk)):
+                k = ci % len(stages)
+                part = names[s:s + chunk]
+                if free_ev[k] is not None:
+                    t0 = time.perf_counter()
+                    free_ev[k].synchronize()
+                    t_wait += time.perf_counter() - t0
+                t0 = time.perf_counter()
+                fill(k, part)
+                t_decode += time.perf_counter() - t0
+                out[s:s + len(part)] = stages[k][:len(part)].to(dev, non_blocking=pin).permute(0, 2, 3, 1)
+                if pin:
+                    free_ev[k] = torch.cuda.Event()
+                    free_ev[k].record(torch.cuda.current_stream(dev))
+        finally:
+            pool.shutdown()
+            for fd in fds:
+                os.close(fd)
+        if stats is not None:
+            stats.update(decode_s=stats.get('decode_s', 0.0) + t_decode, stage_wait_s=stats.get('stage_wait_s', 0.0) + t_wait,
+                         bytes=stats.get('bytes', 0) + len(names) * D * h * w * 4)
         return out
 
 

@@ -47,6 +47,7 @@ def build_parser():
     p.add_argument('--six_dof', action='store_true', help='PredUnlabeledDataset.py variant; writes --save_final_pred')
     p.add_argument('--save_final_pred', default='', type=str)
     p.add_argument('--accuracy_table', default='', type=str, help='directory of per-category records: print CalAccuracy table')
+    p.add_argument('--batch', default=256, type=int, help='images per solve launch; the next batch is read and uploaded meanwhile')
     return p
 
 
@@ -91,15 +92,49 @@ def build_solver(args, rec, subtypes, device):
     return solver, clutter
 
 
-def solve_shard(args, rec, subtypes, names, mesh_of, device):
-    """Clutter score (per subtype) -> grid init -> fused solve for the listed images: [len(names), 10] records."""
+def solve_shard(args, rec, subtypes, names, mesh_of, device, stats=None):
+    """Clutter score (per subtype) -> grid init -> fused solve for the listed images: [len(names), 10] records.
+
+    The images go through in batches of --batch: while batch k is solved, a helper thread reads batch k + 1 from
+    the record into pinned memory and uploads it on a side stream (records.upload_pixel_major), so the file path
+    costs max(read + upload, solve) per batch instead of their sum.  Batches do not change results (every job is
+    independent)."""
+    from concurrent.futures import ThreadPoolExecutor
     solver, clutter = build_solver(args, rec, subtypes, device)
-    feats = rec.upload_pixel_major(names, solver.device)
-    clu = None if solver.cfg.turn_off_clutter else solver.clutter_scores_by_group(feats, mesh_of, clutter)
-    mesh_idx = torch.tensor(mesh_of, dtype=torch.int32, device=solver.device)
-    res = solver.solve_all(feats, None, mesh_idx, clutter_scores=clu)
-    t2 = res.trans_2d if res.trans_2d is not None else torch.zeros((len(names), 2), device=solver.device)
-    return torch.cat([res.packed(), t2], dim=1), dict(solver=solver, result=res, clu=clu, feats=feats)
+    dev = solver.device
+    n, B = len(names), max(1, int(getattr(args, 'batch', 256) or 256))
+    side = torch.cuda.Stream(dev)
+
+    def load(lo, hi):
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(side):
+            feats = rec.upload_pixel_major(names[lo:hi], dev, stats=stats)
+            ready = torch.cuda.Event()
+            ready.record(side)
+        return feats, ready
+
+    solver.engine.reserve(min(B, n), int(solver.grid_theta.shape[1]))
+    solver.prerender()
+    out, clus, inits = [], [], []
+    with ThreadPoolExecutor(max_workers=1) as helper:
+        nxt = helper.submit(load, 0, min(B, n))
+        for lo in range(0, n, B):
+            hi = min(lo + B, n)
+            feats, ready = nxt.result()
+            if hi < n:
+                nxt = helper.submit(load, hi, min(hi + B, n))
+            main = torch.cuda.current_stream(dev)
+            main.wait_event(ready)
+            feats.record_stream(main)
+            clu = None if solver.cfg.turn_off_clutter else solver.clutter_scores_by_group(feats, mesh_of[lo:hi], clutter)
+            mesh_idx = torch.tensor(mesh_of[lo:hi], dtype=torch.int32, device=dev)
+            res = solver.solve_all(feats, None, mesh_idx, clutter_scores=clu)
+            t2 = res.trans_2d if res.trans_2d is not None else torch.zeros((hi - lo, 2), device=dev)
+            out.append(torch.cat([res.packed(), t2], dim=1))
+            clus.append(clu)
+            inits.append(res.init_index)
+    info = dict(solver=solver, init_index=torch.cat(inits), clu=None if clus[0] is None else torch.cat(clus))
+    return torch.cat(out), info
 
 
 def run_sharded(n_items, solve_fn, device):

@@ -1028,7 +1028,11 @@ def test_solve_all_runner_from_files(tmp_path, oracle):
         all_names, mesh_of = solve_all.category_jobs(rec, ['mesh01', 'mesh02'])
         recs, info = solve_all.solve_shard(args, rec, ['mesh01', 'mesh02'], all_names, mesh_of, 'cuda:0')
     assert mesh_of == [0, 0, 0, 1, 1] and recs.shape == (5, 10)
-    got_clu, best = info['clu'].cpu().numpy(), info['result'].init_index.cpu().numpy()
+    got_clu, best = info['clu'].cpu().numpy(), info['init_index'].cpu().numpy()
+    args.batch = 2                                              # three batches (2 + 2 + 1 images), the next one prefetched: same records
+    with records.FeatureRecord(rec_path) as rec:
+        recs_b, _ = solve_all.solve_shard(args, rec, ['mesh01', 'mesh02'], all_names, mesh_of, 'cuda:0')
+    assert torch.equal(recs_b, recs)
     gC, gth = syn.pose_grid(scs[0].distance)
     for i, k in enumerate(mesh_of):
         sc = scs[k]
