@@ -1332,6 +1332,25 @@ __global__ void gather_pose_kernel(int n, const int32_t *gidx, const float *grid
   theta[k] = gridTheta[g];
 }
 
+// Render jobs of one pose block: job (pair i, block pose b) -> its mesh and its index into the grid arrays.
+__global__ void block_jobs_kernel(int n_pairs, int G, int g0, int gb, const int32_t *pair_mesh, const int32_t *pair_grid,
+                                  int32_t *mesh_out, int32_t *gidx_out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_pairs * gb) return;
+  const int i = k / gb, b = k - i * gb;
+  mesh_out[k] = pair_mesh[i];
+  gidx_out[k] = pair_grid[i] * G + g0 + b;
+}
+
+// chunk_live[pair][chunk] = 1 if any pose of the block [g0, g0 + gb) covers a pixel of the chunk (from the stored lists).
+__global__ void chunk_live_kernel(int G, int g0, int gb, int n_chunks, size_t stride, const uint32_t *list,
+                                  const int32_t *cnt, uint8_t *live) {
+  const int sl = blockIdx.x / gb, g = g0 + blockIdx.x % gb;
+  const size_t pg = (size_t)sl * G + g;
+  const uint32_t *l = list + pg * stride;
+  for (int e = threadIdx.x; e < cnt[pg]; e += blockDim.x) live[sl * n_chunks + (int)((l[e] & 0xffffu) / GP_PIX)] = 1;
+}
+
 // Jobs grouped by pre-render slot: order[] lists the job ids slot by slot, slot_start[] the ranges,
 // job_slot[n] the slot of job n (-1: not pre-rendered, evaluated on the fly by grid_kernel).
 __global__ __launch_bounds__(1024) void grid_group_kernel(int N, const int32_t *mesh_idx, const int32_t *grid_idx,
@@ -1369,102 +1388,24 @@ __global__ __launch_bounds__(1024) void grid_group_kernel(int N, const int32_t *
   if (threadIdx.x == 0) work[0] = n_work;
 }
 
-template <int D>
-__global__ __launch_bounds__(1024) void grid_mfma_kernel(int hw, int N, int G, int n_chunks, const int32_t *img_idx,
-                                                         const int32_t *order, const int32_t *slot_start,
-                                                         const float *__restrict__ feat, const float *__restrict__ clu,
-                                                         const float *__restrict__ maps, float *__restrict__ partial,
-                                                         int clutter_on) {
-  __shared__ float cl[GP_TILES][GP_PIX][32];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i = lane & 31, half = lane >> 5;
-  const int sl = blockIdx.x / n_chunks, c = blockIdx.x % n_chunks;
-  const int js = slot_start[sl], ns = slot_start[sl + 1] - js;
-  if (ns == 0) return;
-  const int p0 = c * GP_PIX, np = min(GP_PIX, hw - p0);
-  const int g = (int)blockIdx.y * 512 + wave * 32 + i;  // 16 waves x 32 poses per workgroup, more poses in grid.y
-  const bool gok = g < G;
-  const float *Bp = maps + (((size_t)sl * G + min(g, G - 1)) * hw + p0) * D + half * 4;
-  for (int tg = 0; tg < ns; tg += 32 * GP_TILES) {
-    const float *Ap[GP_TILES];
-#pragma unroll
-    for (int t = 0; t < GP_TILES; ++t) {
-      const int job = order[js + min(tg + t * 32 + i, ns - 1)];
-      const int img = img_idx ? img_idx[job] : job;
-      Ap[t] = feat + ((size_t)img * hw + p0) * D + half * 4;
-    }
-    // clutter scores of the tile's jobs at the chunk's pixels -> LDS [tile][pixel][job row]
-    for (int k = tid; k < GP_TILES * 32 * np; k += blockDim.x) {
-      const int p = k % np, row = (k / np) & 31, t = k / (np * 32);
-      const int job = order[js + min(tg + t * 32 + row, ns - 1)];
-      const int img = img_idx ? img_idx[job] : job;
-      cl[t][p][row] = clutter_on ? clu[(size_t)img * hw + p0 + p] : 0.0f;
-    }
-    __syncthreads();
-    f16v lsum[GP_TILES];
-#pragma unroll
-    for (int t = 0; t < GP_TILES; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) lsum[t][r] = 0.0f;
-    for (int p = 0; p < np; ++p) {
-      f16v acc[GP_TILES];
-#pragma unroll
-      for (int t = 0; t < GP_TILES; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-      const f4 *bq = (const f4 *)(Bp + (size_t)p * D);
-#pragma unroll 4
-      for (int q = 0; q < D / 8; ++q) {
-        const f4 b = bq[2 * q];
-#pragma unroll
-        for (int t = 0; t < GP_TILES; ++t) {
-          const f4 a = ((const f4 *)(Ap[t] + (size_t)p * D))[2 * q];
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
-        }
-      }
-      // C/D layout: column = lane & 31 (pose), row = (r & 3) + 8 * (r >> 2) + 4 * half (job of the tile)
-#pragma unroll
-      for (int t = 0; t < GP_TILES; ++t)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const f4 cv = *(const f4 *)&cl[t][p][8 * k + 4 * half];
-          const float cc[4] = {cv.x, cv.y, cv.z, cv.w};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float o = acc[t][4 * k + r];
-            lsum[t][4 * k + r] += clutter_on ? (fmaxf(o, cc[r]) - fmaxf(0.0f, cc[r])) : o;
-          }
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < GP_TILES; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int jrow = tg + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (jrow < ns && gok) partial[((size_t)c * N + order[js + jrow]) * G + g] = lsum[t][r];
-      }
-    __syncthreads();  // the clutter tile is rewritten by the next pass
-  }
-}
-
-// The same contraction with both operands staged through LDS.  Per pixel the workgroup needs the feature rows
+// Both operands are staged through LDS.  Per pixel the workgroup needs the feature rows
 // of the pass's jobs (A, JTW tiles of 32 rows) and the rendered rows of its poses (B, PTW tiles of 32 rows): each
 // row is read from HBM once, coalesced, by the whole workgroup (one pixel ahead, through registers) instead of
 // once per wave with 16-byte gathers, and wave w multiplies tile (jt, pt) = (w / PTW, w % PTW) out of LDS.  Rows
 // are padded to 132 floats, which makes the 16-byte operand reads of a 16-lane group conflict-free.  For
-// D = 256 a pixel is staged in two halves of 128 features; the k-order of the FMA chains is that of
-// grid_mfma_kernel, so the partial sums are bit-identical to it.
+// D = 256 a pixel is staged in two halves of 128 features.
+// Pose blocks: `maps` holds the renders of Gb consecutive grid poses [g_off, g_off + Gb) of every pair (all G of them
+// when the store fits its budget, otherwise nemo_grid_search renders block after block into the same buffer);
+// `chunk_live` (optional) says per (pair, pixel chunk) whether ANY pose of the block covers a pixel of the chunk --
+// if none does, every object score is 0, every loss term max(0, clu) - max(0, clu) = 0, and the chunk is skipped.
 constexpr int GQ_ROW = 132;
 template <int D>
-__global__ __launch_bounds__(1024) void grid_mfma_lds_kernel(int hw, int N, int G, int n_chunks, int PTW, int JTW,
-                                                             const int32_t *img_idx, const int32_t *order,
+__global__ __launch_bounds__(1024) void grid_mfma_lds_kernel(int hw, int N, int G, int Gb, int g_off, int n_chunks, int PTW,
+                                                             int JTW, const int32_t *img_idx, const int32_t *order,
                                                              const int32_t *slot_start, const float *__restrict__ feat,
                                                              const float *__restrict__ clu,
                                                              const float *__restrict__ maps, float *__restrict__ partial,
-                                                             int clutter_on) {
+                                                             const uint8_t *__restrict__ chunk_live, int clutter_on) {
   extern __shared__ __align__(16) float gq_sm[];
   constexpr int KH = D / 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1473,7 +1414,13 @@ __global__ __launch_bounds__(1024) void grid_mfma_lds_kernel(int hw, int N, int 
   const int js = slot_start[sl], ns = slot_start[sl + 1] - js;
   if (ns == 0) return;
   const int p0 = c * GP_PIX, np = min(GP_PIX, hw - p0);
-  const int g0 = (int)blockIdx.y * PTW * 32;
+  const int g0 = (int)blockIdx.y * PTW * 32;      // first pose of this workgroup, relative to the block
+  if (chunk_live && !chunk_live[sl * n_chunks + c]) {
+    const int ng = min(PTW * 32, Gb - g0);
+    for (int k = tid; k < ns * ng; k += 1024)
+      partial[((size_t)c * N + order[js + k / ng]) * G + g_off + g0 + k % ng] = 0.0f;
+    return;
+  }
   const int nrowsA = JTW * 32, NS = PTW + JTW;  // slab k of 32 rows: A for k < JTW, B after
   float *As = gq_sm, *Bs = gq_sm + nrowsA * GQ_ROW, *cls = gq_sm + NS * 32 * GQ_ROW;
   const int pt = wave % PTW, jt = wave / PTW;
@@ -1489,8 +1436,8 @@ __global__ __launch_bounds__(1024) void grid_mfma_lds_kernel(int hw, int N, int 
         const int img = img_idx ? img_idx[job] : job;
         rp[k] = feat + ((size_t)img * hw + p0) * D + sc4 * 4;
       } else if (k < NS) {
-        const int g = min(g0 + (k - JTW) * 32 + srow, G - 1);
-        rp[k] = maps + (((size_t)sl * G + g) * hw + p0) * D + sc4 * 4;
+        const int g = min(g0 + (k - JTW) * 32 + srow, Gb - 1);
+        rp[k] = maps + (((size_t)sl * Gb + g) * hw + p0) * D + sc4 * 4;
       }
     }
     const float *clp = nullptr;
@@ -1555,7 +1502,7 @@ __global__ __launch_bounds__(1024) void grid_mfma_lds_kernel(int hw, int N, int 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int jrow = tg + jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (jrow < ns && g < G) partial[((size_t)c * N + order[js + jrow]) * G + g] = lsum[r];
+        if (jrow < ns && g < Gb) partial[((size_t)c * N + order[js + jrow]) * G + g_off + g] = lsum[r];
       }
     }
     __syncthreads();  // the next pass restages the LDS
@@ -2054,7 +2001,12 @@ struct nemo_ctx {
   // pre-rendered grid (nemo_grid_prerender)
   int32_t *d_pre_slot, *d_pre_cnt, *d_pre_pairs;
   uint32_t *d_pre_list;
-  float *d_pre_maps;  // dense renders [pairs][G][h*w][D] for the MFMA grid search, or null (over budget)
+  float *d_pre_maps;  // dense renders [pairs][pre_block][h*w][D] for the MFMA grid search, or null (no store / large meshes)
+  int pre_block;      // poses per pair held by d_pre_maps: pre_G (whole grid resident) or a block of it (rendered per call)
+  // block render scratch (job = (pair, pose of the block)); in the resident case freed once the maps are rendered
+  int32_t *d_blk_mesh, *d_blk_gidx, *d_blk_p2f;
+  float *d_blk_C, *d_blk_t, *d_blk_R, *d_blk_T, *d_blk_bary;
+  uint8_t *d_blk_live;  // [pairs][pixel chunks]: does any pose of the current block cover a pixel of the chunk
   const float *pre_gridC, *pre_gridT;
   int pre_G, pre_pairs;
   // grid-search workspace (grown on demand): job grouping and per-chunk partial sums
@@ -2071,7 +2023,7 @@ struct nemo_ctx {
   int device;            // HIP device the context was created on
   int n_cu;              // its compute-unit count (cached: hipGetDeviceProperties is slow)
   // environment switches, read ONCE in nemo_ctx_create (hot calls never call getenv)
-  int env_grid_no_mfma, env_grid_mfma_direct, env_solve_stagger, env_solve_order, env_solve_affinity, env_slot_identity;
+  int env_grid_no_mfma, env_solve_stagger, env_solve_order, env_solve_affinity, env_slot_identity;
   double env_prerender_map_gb;
   char err[512];
 };
@@ -2226,6 +2178,33 @@ static int static_ws_init(nemo_ctx *ctx) {
     }                                                                                           \
   } while (0)
 
+// Renders grid poses [g0, g0 + gb) of every pre-render pair into ctx->d_pre_maps ([pair][gb][h*w][D], zero rows where
+// nothing is covered) and refreshes the per-(pair, pixel chunk) coverage flags of the block.  Launches only.
+static int render_pose_block(nemo_ctx *ctx, const float *d_grid_C, const float *d_grid_theta, int G, int g0, int gb,
+                             hipStream_t st) {
+  const int n_pairs = ctx->pre_pairs;
+  const size_t jobs = (size_t)n_pairs * gb, stride = (size_t)ctx->cfg.win_h * ctx->cfg.win_w, D = (size_t)ctx->cfg.feat_dim;
+  const int n_chunks = (int)((stride + GP_PIX - 1) / GP_PIX);
+  hipLaunchKernelGGL(block_jobs_kernel, dim3((unsigned)((jobs + 255) / 256)), dim3(256), 0, st, n_pairs, G, g0, gb,
+                     (const int32_t *)ctx->d_pre_pairs, (const int32_t *)(ctx->d_pre_pairs + n_pairs), ctx->d_blk_mesh,
+                     ctx->d_blk_gidx);
+  hipLaunchKernelGGL(gather_pose_kernel, dim3((unsigned)((jobs + 255) / 256)), dim3(256), 0, st, (int)jobs,
+                     (const int32_t *)ctx->d_blk_gidx, d_grid_C, d_grid_theta, ctx->d_blk_C, ctx->d_blk_t);
+  hipLaunchKernelGGL(campos_kernel, dim3((unsigned)((jobs + 63) / 64)), dim3(64), 0, st, (const float *)ctx->d_blk_C,
+                     (const float *)ctx->d_blk_t, (const float *)nullptr, (int)jobs, ctx->d_blk_R, ctx->d_blk_T);
+  LAUNCH_PB(raster_kernel, dim3((unsigned)jobs), st, ctx->P, ctx->d_meshes, (const int32_t *)ctx->d_blk_mesh,
+            (const float *)ctx->d_blk_R, (const float *)ctx->d_blk_T, ctx->d_blk_p2f, ctx->d_blk_bary, (float *)nullptr);
+  const size_t npix = jobs * stride, threads = npix * (D / 4);
+  hipLaunchKernelGGL(interpolate_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (int)D, npix, stride,
+                     ctx->d_meshes, (const int32_t *)ctx->d_blk_mesh, (const int32_t *)ctx->d_blk_p2f,
+                     (const float *)ctx->d_blk_bary, ctx->d_pre_maps);
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_blk_live, 0, (size_t)n_pairs * n_chunks, st));
+  hipLaunchKernelGGL(chunk_live_kernel, dim3((unsigned)jobs), dim3(256), 0, st, G, g0, gb, n_chunks, stride,
+                     (const uint32_t *)ctx->d_pre_list, (const int32_t *)ctx->d_pre_cnt, ctx->d_blk_live);
+  HIP_TRY(ctx, hipGetLastError());
+  return NEMO_OK;
+}
+
 extern "C" {
 
 const char *nemo_last_error(const nemo_ctx *ctx) { return ctx ? ctx->err : g_err; }
@@ -2293,7 +2272,6 @@ int nemo_ctx_create(const nemo_config *cfg, nemo_ctx **out) {
   }
   auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
   ctx->env_grid_no_mfma = env_int("NEMO_GRID_NO_MFMA", 0);
-  ctx->env_grid_mfma_direct = env_int("NEMO_GRID_MFMA_DIRECT", 0);
   ctx->env_solve_stagger = env_int("NEMO_SOLVE_STAGGER", 0);
   ctx->env_solve_order = env_int("NEMO_SOLVE_ORDER", 1);
   ctx->env_solve_affinity = env_int("NEMO_SOLVE_AFFINITY", 1);
@@ -2350,8 +2328,17 @@ int nemo_workspace_reserve(nemo_ctx *ctx, int32_t max_jobs, int32_t max_grid_pos
   return reserve_big_scratch(ctx, blocks);
 }
 
+static void free_block_scratch(nemo_ctx *ctx, bool keep_live) {
+  hipFree(ctx->d_blk_mesh); hipFree(ctx->d_blk_gidx); hipFree(ctx->d_blk_p2f); hipFree(ctx->d_blk_C); hipFree(ctx->d_blk_t);
+  hipFree(ctx->d_blk_R); hipFree(ctx->d_blk_T); hipFree(ctx->d_blk_bary);
+  ctx->d_blk_mesh = ctx->d_blk_gidx = ctx->d_blk_p2f = nullptr;
+  ctx->d_blk_C = ctx->d_blk_t = ctx->d_blk_R = ctx->d_blk_T = ctx->d_blk_bary = nullptr;
+  if (!keep_live) { hipFree(ctx->d_blk_live); ctx->d_blk_live = nullptr; }
+}
+
 int nemo_ctx_destroy(nemo_ctx *ctx) {
   if (!ctx) return NEMO_OK;
+  free_block_scratch(ctx, false);
   hipFree(ctx->d_meshes);
   hipFree(ctx->d_counter);
   hipFree(ctx->d_adam);
@@ -2516,27 +2503,27 @@ int nemo_grid_search(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const i
                        ctx->pre_pairs, ctx->d_gs_order, ctx->d_gs_start, ctx->d_gs_jobslot, ctx->d_gs_work);
     d_work = ctx->d_gs_work;
     const int con = (ctx->cfg.clutter && d_clu) ? 1 : 0;
-    if (ctx->env_grid_mfma_direct) {  // earlier variant: operands gathered straight from global memory by every wave
-      const int gy = (G + 511) / 512;  // poses beyond 512 go to further workgroups (grid.y)
-      const dim3 grd((unsigned)(ctx->pre_pairs * n_chunks), (unsigned)gy), blk((unsigned)(64 * (((G < 512 ? G : 512) + 31) / 32)));
-      if (ctx->cfg.feat_dim == 128)
-        hipLaunchKernelGGL((grid_mfma_kernel<128>), grd, blk, 0, st, hw, N, G, n_chunks, d_img_idx, ctx->d_gs_order,
-                           ctx->d_gs_start, d_feat, d_clu, ctx->d_pre_maps, ctx->d_gs_partial, con);
-      else
-        hipLaunchKernelGGL((grid_mfma_kernel<256>), grd, blk, 0, st, hw, N, G, n_chunks, d_img_idx, ctx->d_gs_order,
-                           ctx->d_gs_start, d_feat, d_clu, ctx->d_pre_maps, ctx->d_gs_partial, con);
-    } else {
+    // pose blocks: the whole grid when its renders are resident, otherwise block after block through the same buffer
+    // (render -> contraction -> reuse; everything was allocated by nemo_grid_prerender)
+    for (int g0 = 0; g0 < G; g0 += ctx->pre_block) {
+      const int gb = G - g0 < ctx->pre_block ? G - g0 : ctx->pre_block;
+      if (ctx->pre_block < G) {
+        int rc_ = render_pose_block(ctx, d_grid_C, d_grid_theta, G, g0, gb, st);
+        if (rc_ != NEMO_OK) return rc_;
+      }
       // pose tiles per workgroup (PTW) and job tiles per pass (JTW): 16 waves, at most 8 staged tiles of 32 rows
-      const int PT = (G + 31) / 32, PTW = PT <= 5 ? PT : 4;
+      const int PT = (gb + 31) / 32, PTW = PT <= 5 ? PT : 4;
       const int JTW = (16 / PTW) < (8 - PTW) ? (16 / PTW) : (8 - PTW);
       const dim3 grd((unsigned)(ctx->pre_pairs * n_chunks), (unsigned)((PT + PTW - 1) / PTW)), blk(1024);
       const size_t sm = ((size_t)(PTW + JTW) * 32 * GQ_ROW + (size_t)JTW * 32) * sizeof(float);
       if (ctx->cfg.feat_dim == 128)
-        hipLaunchKernelGGL((grid_mfma_lds_kernel<128>), grd, blk, sm, st, hw, N, G, n_chunks, PTW, JTW, d_img_idx,
-                           ctx->d_gs_order, ctx->d_gs_start, d_feat, d_clu, ctx->d_pre_maps, ctx->d_gs_partial, con);
+        hipLaunchKernelGGL((grid_mfma_lds_kernel<128>), grd, blk, sm, st, hw, N, G, gb, g0, n_chunks, PTW, JTW, d_img_idx,
+                           ctx->d_gs_order, ctx->d_gs_start, d_feat, d_clu, ctx->d_pre_maps, ctx->d_gs_partial,
+                           ctx->d_blk_live, con);
       else
-        hipLaunchKernelGGL((grid_mfma_lds_kernel<256>), grd, blk, sm, st, hw, N, G, n_chunks, PTW, JTW, d_img_idx,
-                           ctx->d_gs_order, ctx->d_gs_start, d_feat, d_clu, ctx->d_pre_maps, ctx->d_gs_partial, con);
+        hipLaunchKernelGGL((grid_mfma_lds_kernel<256>), grd, blk, sm, st, hw, N, G, gb, g0, n_chunks, PTW, JTW, d_img_idx,
+                           ctx->d_gs_order, ctx->d_gs_start, d_feat, d_clu, ctx->d_pre_maps, ctx->d_gs_partial,
+                           ctx->d_blk_live, con);
     }
     hipLaunchKernelGGL(grid_finish_kernel, dim3(N), dim3(256), 0, st, hw, ctx->P.inv_hw, N, G, n_chunks, d_img_idx,
                        ctx->d_gs_jobslot, d_clu, ctx->d_gs_partial, ctx->d_pre_cnt, d_losses, ctx->d_counter, con);
@@ -2577,6 +2564,8 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
   if (!ctx) return fail(nullptr, NEMO_ERR_ARG, "nemo_grid_prerender: null ctx");
   hipFree(ctx->d_pre_slot); hipFree(ctx->d_pre_cnt); hipFree(ctx->d_pre_pairs); hipFree(ctx->d_pre_list);
   hipFree(ctx->d_pre_maps);
+  free_block_scratch(ctx, false);
+  ctx->pre_block = 0;
   ctx->d_pre_slot = ctx->d_pre_cnt = ctx->d_pre_pairs = nullptr;
   ctx->d_pre_list = nullptr;
   ctx->d_pre_maps = nullptr;
@@ -2613,45 +2602,45 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
   ctx->pre_gridC = d_grid_C; ctx->pre_gridT = d_grid_theta;
   ctx->pre_G = G; ctx->pre_pairs = n_pairs;
   // Dense renders for the MFMA grid search: campos -> rasterize -> interpolate with the standalone kernels
-  // (uncovered pixels are zero rows).  Skipped when they would not fit the budget (NEMO_PRERENDER_MAP_GB,
-  // default 48): the list path above then serves the grid search.
-  {
+  // (uncovered pixels are zero rows).  Budget NEMO_PRERENDER_MAP_GB (default 48): when all G poses of every pair
+  // fit, they are rendered here, once; otherwise the buffer holds a BLOCK of poses (a multiple of 32, the matrix-core
+  // pose tile) and nemo_grid_search renders block after block into it.  Large (BIG) meshes keep the list path.
+  if (!ctx->P.big && n_pairs <= GP_MAX_PAIRS) {
     const double budget = ctx->env_prerender_map_gb * 1073741824.0;
-    const size_t jobs = (size_t)n_pairs * G, D = (size_t)ctx->cfg.feat_dim;
-    const double need = (double)jobs * stride * D * 4.0;
-    if (need <= budget && n_pairs <= GP_MAX_PAIRS) {
-      std::vector<int32_t> h_mesh(jobs), h_gidx(jobs);
-      std::vector<float> h_C, h_t;
-      for (int i = 0; i < n_pairs; ++i)
-        for (int g = 0; g < G; ++g) { h_mesh[(size_t)i * G + g] = h_pair_mesh[i]; h_gidx[(size_t)i * G + g] = h_pair_grid[i] * G + g; }
-      int32_t *d_mesh = nullptr, *d_gidx = nullptr, *d_p2f = nullptr;
-      float *d_C = nullptr, *d_t = nullptr, *d_R = nullptr, *d_T = nullptr, *d_bary = nullptr;
-      hipStream_t st = (hipStream_t)stream;
-      auto cleanup = [&]() { hipFree(d_mesh); hipFree(d_gidx); hipFree(d_p2f); hipFree(d_C); hipFree(d_t); hipFree(d_R); hipFree(d_T); hipFree(d_bary); };
-      hipError_t e = hipMalloc(&d_mesh, jobs * 4);
-      if (e == hipSuccess) e = hipMalloc(&d_gidx, jobs * 4);
-      if (e == hipSuccess) e = hipMalloc(&d_C, jobs * 12);
-      if (e == hipSuccess) e = hipMalloc(&d_t, jobs * 4);
-      if (e == hipSuccess) e = hipMalloc(&d_R, jobs * 36);
-      if (e == hipSuccess) e = hipMalloc(&d_T, jobs * 12);
-      if (e == hipSuccess) e = hipMalloc(&d_p2f, jobs * stride * 4);
-      if (e == hipSuccess) e = hipMalloc(&d_bary, jobs * stride * 12);
-      if (e == hipSuccess) e = hipMalloc(&ctx->d_pre_maps, (size_t)need);
-      if (e == hipSuccess) e = hipMemcpyAsync(d_mesh, h_mesh.data(), jobs * 4, hipMemcpyHostToDevice, st);
-      if (e == hipSuccess) e = hipMemcpyAsync(d_gidx, h_gidx.data(), jobs * 4, hipMemcpyHostToDevice, st);
-      if (e != hipSuccess) { cleanup(); hipFree(ctx->d_pre_maps); ctx->d_pre_maps = nullptr; return hip_fail(ctx, e, "nemo_grid_prerender: maps"); }
-      hipLaunchKernelGGL(gather_pose_kernel, dim3((unsigned)((jobs + 255) / 256)), dim3(256), 0, st, (int)jobs, d_gidx,
-                         d_grid_C, d_grid_theta, d_C, d_t);
-      hipLaunchKernelGGL(campos_kernel, dim3((unsigned)((jobs + 63) / 64)), dim3(64), 0, st, d_C, d_t, (const float *)nullptr,
-                         (int)jobs, d_R, d_T);
-      LAUNCH_PB(raster_kernel, dim3((unsigned)jobs), st, ctx->P, ctx->d_meshes, d_mesh, d_R, d_T, d_p2f, d_bary, (float *)nullptr);
-      const size_t npix = jobs * stride, threads = npix * (D / 4);
-      hipLaunchKernelGGL(interpolate_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (int)D, npix, stride,
-                         ctx->d_meshes, d_mesh, d_p2f, d_bary, ctx->d_pre_maps);
-      e = hipGetLastError();
-      if (e == hipSuccess) e = hipStreamSynchronize(st);
-      cleanup();
-      if (e != hipSuccess) { hipFree(ctx->d_pre_maps); ctx->d_pre_maps = nullptr; return hip_fail(ctx, e, "nemo_grid_prerender: render maps"); }
+    const size_t D = (size_t)ctx->cfg.feat_dim;
+    const double per_pose = (double)n_pairs * stride * D * 4.0;  // one pose of every pair
+    long block = (long)(budget / per_pose);
+    if (block >= G) block = G; else block = (block / 32) * 32;
+    if (block >= 32 || block == G) {
+      const size_t jobs = (size_t)n_pairs * block;
+      const int n_chunks = (int)((stride + GP_PIX - 1) / GP_PIX);
+      hipError_t e = hipMalloc(&ctx->d_blk_mesh, jobs * 4);
+      if (e == hipSuccess) e = hipMalloc(&ctx->d_blk_gidx, jobs * 4);
+      if (e == hipSuccess) e = hipMalloc(&ctx->d_blk_C, jobs * 12);
+      if (e == hipSuccess) e = hipMalloc(&ctx->d_blk_t, jobs * 4);
+      if (e == hipSuccess) e = hipMalloc(&ctx->d_blk_R, jobs * 36);
+      if (e == hipSuccess) e = hipMalloc(&ctx->d_blk_T, jobs * 12);
+      if (e == hipSuccess) e = hipMalloc(&ctx->d_blk_p2f, jobs * stride * 4);
+      if (e == hipSuccess) e = hipMalloc(&ctx->d_blk_bary, jobs * stride * 12);
+      if (e == hipSuccess) e = hipMalloc(&ctx->d_blk_live, (size_t)n_pairs * n_chunks);
+      if (e == hipSuccess) e = hipMalloc(&ctx->d_pre_maps, (size_t)(per_pose * (double)block));
+      if (e != hipSuccess) {
+        free_block_scratch(ctx, false);
+        hipFree(ctx->d_pre_maps);
+        ctx->d_pre_maps = nullptr;
+        return hip_fail(ctx, e, "nemo_grid_prerender: dense maps");
+      }
+      ctx->pre_block = (int)block;
+      if (block == G) {  // resident: render now, then drop the render scratch (the chunk flags stay)
+        int rc_ = render_pose_block(ctx, d_grid_C, d_grid_theta, G, 0, G, (hipStream_t)stream);
+        hipError_t se = hipStreamSynchronize((hipStream_t)stream);
+        free_block_scratch(ctx, true);
+        if (rc_ != NEMO_OK || se != hipSuccess) {
+          hipFree(ctx->d_pre_maps);
+          ctx->d_pre_maps = nullptr;
+          return rc_ != NEMO_OK ? rc_ : hip_fail(ctx, se, "nemo_grid_prerender: render maps");
+        }
+      }
     }
   }
   return NEMO_OK;

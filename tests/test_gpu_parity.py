@@ -1073,6 +1073,42 @@ def test_dense_pose_grid_search(oracle):
         assert best[i] == bo
 
 
+def test_dense_grid_tiled_over_pose_blocks(oracle, monkeypatch):
+    """BASELINE config 4 with several classes: the dense renders of all (mesh, pose) pairs do not fit the map budget,
+    so nemo_grid_search renders them block after block (a multiple of 32 poses) into the buffer nemo_grid_prerender
+    sized, and runs the matrix-core contraction per block.  Two classes with their own meshes and grids, 288 poses,
+    a budget that forces 3 blocks: every loss against the oracle, same argmin, bit-identical to the resident store."""
+    from nemo_amd.engine import PoseEngine
+    a = make_scene('car', n_img=2, seed=81)
+    b = make_scene('bus', n_img=2, seed=82, number_vertices=500)
+    grids = [syn.pose_grid(sc.distance, n_azim=24, n_elev=4, n_theta=3) for sc in (a, b)]
+    G = len(grids[0][1])
+    assert G == 288
+    dC, dth = _dev(np.stack([g[0] for g in grids])), _dev(np.stack([g[1] for g in grids]))
+    feats, clus = _dev(np.concatenate([a.feats, b.feats])), _dev(np.concatenate([a.clus, b.clus]))
+    mesh = _dev([0, 0, 1, 1], torch.int32)
+    out = {}
+    for mode, gb in (('tiled', '0.15'), ('resident', '48')):
+        monkeypatch.setenv('NEMO_PRERENDER_MAP_GB', gb)       # read once, at context creation
+        eng = PoseEngine(a.geo.S, (a.geo.h, a.geo.w), a.D)
+        eng.register_mesh(a.verts, a.faces, a.bank)
+        eng.register_mesh(b.verts, b.faces, b.bank)
+        eng.grid_prerender(dC, dth, [(0, 0), (1, 1)])
+        free0 = torch.cuda.mem_get_info()[0]
+        out[mode] = eng.grid_search(feats, clus, dC, dth, mesh_idx=mesh, grid_idx=mesh)
+        eng.grid_search(feats, clus, dC, dth, mesh_idx=mesh, grid_idx=mesh, losses=out[mode][3].clone())
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info()[0] >= free0 - (8 << 20)          # block rendering allocates nothing (torch outputs aside)
+    # 2 pairs x 1536 px x 128 x 4 B = 1.5 MB per pose: 0.15 GB hold 102 -> 96 poses per block, 288 poses = 3 blocks
+    assert torch.equal(out['tiled'][3], out['resident'][3]) and torch.equal(out['tiled'][2], out['resident'][2])
+    best, losses = out['tiled'][2].cpu().numpy(), out['tiled'][3].cpu().numpy()
+    for k in range(4):
+        sc, (gC, gth) = ((a, grids[0]) if k < 2 else (b, grids[1]))
+        bo, lo = oracle.grid_search(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[k % 2], sc.clus[k % 2], gC, gth)
+        assert np.abs(losses[k] - lo).max() <= REL * np.abs(lo).max()
+        assert best[k] == bo
+
+
 def test_large_mesh_256d_double_resolution(oracle):
     """BASELINE config 5 shape: subdivided cuboid (10 466 vertices, 19 872 faces), 256-d features, 160x200
     window of a 200x200 raster, clutter loss.  The mesh tables do not fit the LDS, so the kernels run in their

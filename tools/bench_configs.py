@@ -4,7 +4,7 @@ one MI355X, inputs resident in HBM.  Parity for these shapes is in tests/test_gp
 (test_multicuboid_argmin_over_meshes, test_dense_pose_grid_search, test_large_mesh_256d_double_resolution);
 this script only measures.
 
-    python tools/bench_configs.py [multi] [dense] [big]
+    python tools/bench_configs.py [multi] [dense] [dense12] [big]
 """
 import json
 import os
@@ -89,9 +89,58 @@ def dense(n_images=1024, seed=4):
     t_pre = time.perf_counter() - t0
     dt, _ = timed(lambda: eng.grid_search(feats, clu, dC, dth, mesh_idx=mesh_idx, grid_idx=mesh_idx))
     G = len(gth)
-    flops = 2.0 * cfg.feat_dim * G * n_images * eng.h * eng.w
-    return {'config': 'dense pose grid', 'images': n_images, 'poses_per_image': G, 'prerender_seconds': t_pre,
-            'seconds': dt, 'pose_evaluations_per_s': n_images * G / dt, 'useful_TFLOPs': flops / dt / 1e12}
+    eng.counter_reset()
+    eng.grid_search(feats, clu, dC, dth, mesh_idx=mesh_idx, grid_idx=mesh_idx)
+    cov = eng.counter_read()                                  # covered (pixel, pose, image) triples of one search
+    return {'config': 'dense pose grid, one class', 'images': n_images, 'poses_per_image': G, 'prerender_seconds': t_pre,
+            'seconds': dt, 'pose_evaluations_per_s': n_images * G / dt,
+            'window_TFLOPs': 2.0 * cfg.feat_dim * G * n_images * eng.h * eng.w / dt / 1e12,
+            'useful_TFLOPs_covered_pixels_only': 2.0 * cfg.feat_dim * cov / dt / 1e12}
+
+
+def dense12(n_images=1024, seed=4):
+    """configs[3] on the 12-class workload: 9720 poses x 12 meshes of dense renders (478 GB) do not fit, so the grid
+    search renders pose blocks into the NEMO_PRERENDER_MAP_GB buffer and contracts them on the matrix cores block by
+    block.  Also timed: the list path (no dense maps) the same search used to fall back to."""
+    rng = np.random.default_rng(seed)
+    cfg = SolverConfig()
+    out = {}
+    for mode in ('tiled_matrix_core', 'list_path'):
+        os.environ['NEMO_PRERENDER_MAP_GB'] = '48'
+        os.environ['NEMO_GRID_NO_MFMA'] = '1' if mode == 'list_path' else '0'
+        s = BatchPoseSolver(cfg)
+        gCs, gts = [], []
+        for c in syn.CATEGORIES:
+            v, f = syn.class_mesh(c, 1000)
+            d = syn.DISTANCE_RENDER[c]
+            s.add_mesh(v, f, syn.unit_rows(np.random.default_rng(seed + 1), len(v), cfg.feat_dim), d)
+            gC, gth = syn.pose_grid(d, n_azim=36, n_elev=9, n_theta=6, distances=tuple(d * x for x in (0.8, 0.9, 1.0, 1.1, 1.2)))
+            gCs.append(gC); gts.append(gth)
+        dC, dth = torch.as_tensor(np.stack(gCs)).cuda().contiguous(), torch.as_tensor(np.stack(gts)).cuda().contiguous()
+        cats = [syn.CATEGORIES[i % 12] for i in range(n_images)]
+        mesh_idx = torch.as_tensor((np.arange(n_images) % 12).astype(np.int32)).cuda()
+        feats = _render_features(s, mesh_idx, gt_poses(np.random.default_rng(seed + 2), cats), np.random.default_rng(seed + 3), 0.5)
+        eng = s.engine
+        clu = eng.clutter_score(feats, s.clutter_vector(torch.as_tensor(syn.unit_rows(rng, 64, cfg.feat_dim)).cuda()))
+        G = dth.shape[1]
+        eng.reserve(n_images, G)
+        t0 = time.perf_counter()
+        eng.grid_prerender(dC, dth, [(m, m) for m in range(12)])
+        torch.cuda.synchronize()
+        t_pre = time.perf_counter() - t0
+        n = n_images if mode != 'list_path' else 128          # the list path is slow: time a slice of the images
+        idx = torch.arange(n, dtype=torch.int32, device='cuda')
+        run = lambda: eng.grid_search(feats, clu, dC, dth, img_idx=idx, mesh_idx=mesh_idx[:n].contiguous(),  # noqa: E731
+                                      grid_idx=mesh_idx[:n].contiguous())
+        dt, res = timed(run, reps=1)
+        eng.counter_reset(); run(); cov = eng.counter_read()
+        out[mode] = {'images': n, 'poses_per_image': G, 'prerender_seconds': t_pre, 'seconds': dt,
+                     'pose_evaluations_per_s': n * G / dt, 'useful_TFLOPs_covered_pixels_only': 2.0 * cfg.feat_dim * cov / dt / 1e12,
+                     'best': res[2][:8].tolist()}
+        del s, eng, feats, clu
+        torch.cuda.empty_cache()
+    out['same_argmin_on_the_first_images'] = out['tiled_matrix_core']['best'] == out['list_path']['best']
+    return {'config': 'dense pose grid, 12 classes (9720 poses x 12 meshes)', **out}
 
 
 def big(n_images=512, steps=300, seed=5):
@@ -103,17 +152,19 @@ def big(n_images=512, steps=300, seed=5):
     s.add_mesh(v, f, syn.unit_rows(rng, len(v), 256), syn.DISTANCE_RENDER['car'])
     mesh_idx = torch.zeros(n_images, dtype=torch.int32, device='cuda')
     feats = _render_features(s, mesh_idx, gt_poses(rng, ['car'] * n_images), rng, 0.5, chunk=32)
-    clutter = s.clutter_vector(torch.as_tensor(syn.unit_rows(rng, 64, 256)).cuda())
+    # config 5 keeps the K-vector clutter bank: score = max over the K vectors (lib/MeshUtils.py:273-275), the
+    # pixels x clutter-bank contraction on the matrix cores
+    clutter = torch.as_tensor(syn.unit_rows(rng, 64, 256)).cuda()
     eng = s.engine
     eng.counter_reset()
     dt, res = timed(lambda: s.solve_all(feats, clutter, mesh_idx), reps=1)
     cov = eng.counter_read() / 2  # warm-up + one timed pass
-    return {'config': 'subdivided cuboid, 256-d, 160x200 window', 'images': n_images, 'V': int(len(v)), 'F': int(len(f)),
+    return {'config': 'subdivided cuboid, 256-d, 160x200 window, 64-vector clutter bank (max over K)', 'images': n_images, 'V': int(len(v)), 'F': int(len(f)),
             'seconds': dt, 'solves_per_s': n_images / dt, 'finite': bool(torch.isfinite(res.campos).all()),
             'covered_pixel_evaluations': cov, 'algorithmic_GBps': cov * eng.bytes_per_covered_pixel() / dt / 1e9}
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['multi', 'dense', 'big']
+    which = sys.argv[1:] or ['multi', 'dense', 'dense12', 'big']
     for name in which:
-        print(json.dumps({name: {'multi': multi, 'dense': dense, 'big': big}[name]()}), flush=True)
+        print(json.dumps({name: {'multi': multi, 'dense': dense, 'dense12': dense12, 'big': big}[name]()}), flush=True)
