@@ -102,7 +102,6 @@ def dense12(n_images=1024, seed=4):
     """configs[3] on the 12-class workload: 9720 poses x 12 meshes of dense renders (478 GB) do not fit, so the grid
     search renders pose blocks into the NEMO_PRERENDER_MAP_GB buffer and contracts them on the matrix cores block by
     block.  Also timed: the list path (no dense maps) the same search used to fall back to."""
-    rng = np.random.default_rng(seed)
     cfg = SolverConfig()
     out = {}
     for mode in ('tiled_matrix_core', 'list_path'):
@@ -121,7 +120,7 @@ def dense12(n_images=1024, seed=4):
         mesh_idx = torch.as_tensor((np.arange(n_images) % 12).astype(np.int32)).cuda()
         feats = _render_features(s, mesh_idx, gt_poses(np.random.default_rng(seed + 2), cats), np.random.default_rng(seed + 3), 0.5)
         eng = s.engine
-        clu = eng.clutter_score(feats, s.clutter_vector(torch.as_tensor(syn.unit_rows(rng, 64, cfg.feat_dim)).cuda()))
+        clu = eng.clutter_score(feats, s.clutter_vector(torch.as_tensor(syn.unit_rows(np.random.default_rng(seed + 4), 64, cfg.feat_dim)).cuda()))
         G = dth.shape[1]
         eng.reserve(n_images, G)
         t0 = time.perf_counter()
