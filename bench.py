@@ -66,10 +66,12 @@ def cpu_baseline(wl, n_sample):
     [t.start() for t in th]
     [t.join() for t in th]
     dt = time.perf_counter() - t0
-    return {'value': n_sample / dt, 'unit': 'solves/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{n_sample} images of the same workload (144-pose init + {s.cfg.total_epochs} Adam steps each), '
-                      f'{cores} host threads (the oracle is single-threaded per image; ctypes releases the GIL), '
-                      f'{dt:.1f} s wall; host has {os.cpu_count()} logical CPUs'}
+    return {'value': n_sample / dt, 'unit': 'solves/s', 'cores': cores, 'per_core': n_sample / dt / cores, 'kind': 'port',
+            'sample': f'{n_sample} images of the same workload, i.e. the 12-class mix of BASELINE configs[1] (configs[0], the '
+                      f"reference's own CPU-runnable case, is 16 car images: same per-image work, one class), 144-pose init + "
+                      f'{s.cfg.total_epochs} Adam steps each, {cores} host threads (the oracle is single-threaded per image; '
+                      f'ctypes releases the GIL), {dt:.1f} s wall; host has {os.cpu_count()} logical CPUs.  The port runs a '
+                      f'hand-derived backward, which is faster than the torch-autograd op sequence of the reference'}
 
 
 def from_files_leg(n_images, dev, batch):
@@ -163,12 +165,15 @@ def launch_ranks(n_gpus, argv):
     return subprocess.call(cmd, env=env)
 
 
+PMC_FILE = 'profiles/r02_pmc_traffic.json'
+
+
 def pmc_traffic(cov_steps):
-    """HBM bytes per launch of the solve kernel from the committed PMC passes (profiles/r01_pmc_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate runs of this workload, FETCH_SIZE doubled as the
-    gfx950 note in MI355X_MICROARCH.md prescribes), scaled by this launch's covered-pixel-steps.  bench.py
-    cannot collect counters itself; None if the file is missing."""
-    fn = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
+    """HBM bytes per launch of the solve kernel, SCALED from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE
+    and WRITE_SIZE in separate runs of this workload, FETCH_SIZE doubled as the gfx950 note in MI355X_MICROARCH.md
+    prescribes): bytes per covered pixel-step of that pass x this launch's covered pixel-steps.  bench.py cannot
+    collect counters itself; None if the file is missing."""
+    fn = os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_FILE)
     try:
         with open(fn) as f:
             per = json.load(f)['solve_kernel']['hbm_bytes_per_covered_pixel_step']
@@ -284,8 +289,14 @@ def main():
                        + (f' [REHEARSAL: {world} ranks share one GPU, gloo]' if args.share_gpu else '')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(cov_steps), 'kernel': 'solve_kernel',
+                         'traffic_source': f'scaled from the committed PMC pass {PMC_FILE} (not read during this run)',
                          'kernel_ms': solve_ms, 'algorithmic_bytes_per_launch': alg_bytes,
-                         'covered_pixel_steps_per_launch': cov_steps},
+                         'covered_pixel_steps_per_launch': cov_steps,
+                         # what the resident jobs (one workgroup per CU) re-read every Adam step, against the 256 MiB
+                         # Infinity Cache: FETCH_SIZE counts L2 misses whether the Infinity Cache or HBM serves them,
+                         # so `frac` (algorithmic bytes / time) is an upper bound on DRAM utilisation
+                         'working_set_bytes': float(min(args.images, 256)) * alg_bytes / max(1, args.images * solver.cfg.total_epochs),
+                         'infinity_cache_bytes': 256 * 2 ** 20},
             'quality': {'finite_fraction': ok, 'median_err_deg_vs_synthetic_gt': float(np.degrees(np.median(errs)))},
         }
         if world == 1 and args.from_files_images > 0:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turn the two PMC passes (tools/pmc.sh fetch* FETCH_SIZE / write* WRITE_SIZE of tools/prof_solve.py) into
-profiles/r01_pmc_traffic.json: per-kernel counter sums in KB and the solve kernel's HBM bytes per covered
+profiles/rNN_pmc_traffic.json: per-kernel counter sums in KB and the solve kernel's HBM bytes per covered
 pixel-step (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
 usage: tools/pmc_summary.py <fetch_dir> <write_dir> <covered_pixel_steps> <out.json>"""
 import collections
