@@ -156,11 +156,12 @@ class BatchPoseSolver:
         self.grid_theta = torch.as_tensor(np.stack(self._grids_t)).to(self.device).contiguous()
         return mid
 
-    def prerender(self):
+    def prerender(self, force: bool = False):
         """get_pre_render_samples (code/MeshPoseSolveAll.py:62-82), once per set of meshes: every mesh's
-        coverage under each of its grid poses.  A no-op when the store is current."""
+        coverage under each of its grid poses.  A no-op when the store is current; the store bakes in the bank
+        and grid CONTENTS, so after changing those tensors in place pass force=True."""
         key = (self.grid_C.data_ptr(), self.grid_theta.data_ptr(), len(self._grids_C))
-        if getattr(self, '_pre_key', None) != key:
+        if force or getattr(self, '_pre_key', None) != key:
             self.engine.grid_prerender(self.grid_C, self.grid_theta, [(m, m) for m in range(len(self._grids_C))])
             self._pre_key = key
 
