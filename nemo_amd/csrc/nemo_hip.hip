@@ -2604,14 +2604,17 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
   // Dense renders for the MFMA grid search: campos -> rasterize -> interpolate with the standalone kernels
   // (uncovered pixels are zero rows).  Budget NEMO_PRERENDER_MAP_GB (default 48): when all G poses of every pair
   // fit, they are rendered here, once; otherwise the buffer holds a BLOCK of poses (a multiple of 32, the matrix-core
-  // pose tile) and nemo_grid_search renders block after block into it.  Large (BIG) meshes keep the list path.
-  if (!ctx->P.big && n_pairs <= GP_MAX_PAIRS) {
+  // pose tile) and nemo_grid_search renders block after block into it.  Large (BIG) meshes render at most
+  // BIG_MAX_BLOCKS (pair, pose) jobs per launch (one table slice per workgroup), which bounds their block.
+  if (n_pairs <= GP_MAX_PAIRS) {
     const double budget = ctx->env_prerender_map_gb * 1073741824.0;
     const size_t D = (size_t)ctx->cfg.feat_dim;
     const double per_pose = (double)n_pairs * stride * D * 4.0;  // one pose of every pair
     long block = (long)(budget / per_pose);
+    if (ctx->P.big && block > (long)(BIG_MAX_BLOCKS / (unsigned)n_pairs)) block = (long)(BIG_MAX_BLOCKS / (unsigned)n_pairs);
     if (block >= G) block = G; else block = (block / 32) * 32;
-    if (block >= 32 || block == G) {
+    if (ctx->P.big && block > 0 && reserve_big_scratch(ctx, (size_t)n_pairs * block) != NEMO_OK) block = 0;
+    if (block >= 32 || (block == G && block > 0)) {
       const size_t jobs = (size_t)n_pairs * block;
       const int n_chunks = (int)((stride + GP_PIX - 1) / GP_PIX);
       hipError_t e = hipMalloc(&ctx->d_blk_mesh, jobs * 4);
