@@ -481,6 +481,50 @@ def test_empty_batch_and_errors():
     assert torch.isfinite(loss).all()
 
 
+def test_engine_argument_checks():
+    """PoseEngine refuses mis-shaped inputs before any pointer reaches a kernel: feature maps in the reference's
+    [n, D, h, w] layout instead of pixel-major, per-job arrays of the wrong length, a clutter map of another size,
+    index values outside what they index (checked on request: it reads the tensors back); device='cuda' (no index)
+    is the current device; nemo_mesh_register itself validates face indices."""
+    import ctypes as C
+    from nemo_amd import _lib
+    from nemo_amd.engine import PoseEngine
+    sc = make_scene(n_img=2)
+    eng = PoseEngine(sc.geo.S, (sc.geo.h, sc.geo.w), sc.D, device='cuda', validate_indices=True)
+    assert eng.device == torch.device('cuda', torch.cuda.current_device())
+    eng.register_mesh(sc.verts, sc.faces, sc.bank)
+    feats, clus = _dev(sc.feats), _dev(sc.clus)
+    C0, th0 = _dev(np.array([[0, 0, sc.distance]] * 2)), _dev(np.zeros(2))
+    loss, _, _ = eng.score_fwd_bwd(feats, clus, C0, th0)                       # well-formed: fine
+    assert torch.isfinite(loss).all()
+    with pytest.raises(ValueError, match='pixel-major'):
+        eng.score_fwd_bwd(feats.permute(0, 3, 1, 2).contiguous(), clus, C0, th0)
+    with pytest.raises(ValueError, match='clu'):
+        eng.score_fwd_bwd(feats, clus[:, :-1].contiguous(), C0, th0)
+    with pytest.raises(ValueError, match='theta'):
+        eng.score_fwd_bwd(feats, clus, C0, _dev(np.zeros(3)))
+    with pytest.raises(ValueError, match='feature maps'):
+        eng.score_fwd_bwd(feats, clus, _dev(np.zeros((3, 3))), _dev(np.zeros(3)))      # 3 jobs, 2 images, no img_idx
+    with pytest.raises(ValueError, match='img_idx'):
+        eng.score_fwd_bwd(feats, clus, C0, th0, img_idx=_dev([0, 2], torch.int32))     # image 2 of 2
+    with pytest.raises(ValueError, match='mesh_idx'):
+        eng.score_fwd_bwd(feats, clus, C0, th0, mesh_idx=_dev([0, 1], torch.int32))    # mesh 1 of 1
+    with pytest.raises(ValueError, match='cbank'):
+        eng.clutter_score(feats, _dev(np.zeros((3, sc.D + 1))))
+    gC, gth = syn.pose_grid(sc.distance)
+    with pytest.raises(ValueError, match='grid_C'):
+        eng.grid_search(feats, clus, _dev(gC[None, :100]), _dev(gth[None]))
+    # the C ABI checks the faces it is given (a face pointing past the vertex array would read out of bounds)
+    v, b = _dev(sc.verts), _dev(sc.bank)
+    bad = sc.faces.copy(); bad[5, 1] = len(sc.verts)
+    f = _dev(bad, torch.int32)
+    rc = eng.lib.nemo_mesh_register(eng.ctx, C.c_void_p(v.data_ptr()), len(sc.verts), C.c_void_p(f.data_ptr()), len(bad),
+                                    C.c_void_p(b.data_ptr()))
+    assert rc == -1 and b'face 5' in eng.lib.nemo_last_error(eng.ctx)
+    loss2, _, _ = eng.score_fwd_bwd(feats, clus, C0, th0)                      # the engine is unharmed
+    assert torch.equal(loss, loss2)
+
+
 def test_hot_calls_do_not_allocate():
     """include/nemo_hip.h: no hot entry point allocates, frees or synchronises.  After nemo_workspace_reserve a
     first batch (warm-up: code objects, torch's cache) and then a LARGER second batch run through clutter score,

@@ -263,3 +263,34 @@ def test_accuracy_table_matches_reference_stdout(tmp_path):
         want = f.read()
     assert text + '\n' == want
     assert rows[3, -1] == sum(len(e) for e in errs.values())
+
+
+def test_feature_record_direct_reads(tmp_path):
+    """records.FeatureRecord: members of an uncompressed .npz (what np.savez / ExtractFeatures.py:223 writes) are read
+    with pread straight from the file, a compressed record goes through the zip reader; both give the maps bit for bit,
+    pixel-major, through the double-buffered upload (chunks smaller than the record, several reader threads), and a
+    map of the wrong shape is refused."""
+    import torch
+    from nemo_amd import records
+    rng = np.random.default_rng(0)
+    feats = {'img%d' % i: rng.standard_normal((16, 5, 7)).astype(np.float32) for i in range(10)}
+    meta = ({'mesh01': np.zeros((3, 16), np.float32)}, {'mesh01': np.zeros((2, 16), np.float32)}, {'mesh01': list(feats)})
+    ref = np.stack([feats[n].transpose(1, 2, 0) for n in feats])
+    for compressed in (False, True):
+        p = str(tmp_path / ('r%d.npz' % compressed))
+        records.write_feature_record(p, *meta, feats)
+        if compressed:
+            with np.load(p) as z:
+                np.savez_compressed(p, **{k: z[k] for k in z.files})
+        with records.FeatureRecord(p) as r:
+            lay = r._layout('img0')
+            assert (lay is None) == compressed and r.feature_shape('img3') == (16, 5, 7)
+            for chunk, workers in ((3, 4), (64, 1)):
+                out = r.upload_pixel_major(list(feats), 'cpu', chunk=chunk, workers=workers)
+                assert out.shape == (10, 5, 7, 16) and np.array_equal(out.numpy(), ref)
+            dst = np.empty((16, 5, 7), np.float32)
+            r.read_feature_into('img7', dst)
+            assert np.array_equal(dst, feats['img7'])
+            with pytest.raises(ValueError):
+                r.read_feature_into('img7', np.empty((16, 7, 5), np.float32))
+            assert r.names('mesh01') == list(feats)

@@ -237,3 +237,32 @@ def test_solve6_oracle_gradients_and_descent():
     assert np.array_equal(tr6[0, 0:4], tr4[0, 0:4]) and tr6[0, 6] == tr4[0, 4]
     assert np.array_equal(tr6[0, 7:11], tr4[0, 5:9])          # same first gradient in (C, theta)
     assert tr6[-1, 6] < tr6[0, 6]                               # it descends
+
+
+def test_rasterizer_lineages_agree_on_random_soups_hypothesis(oracle):
+    """Property test (hypothesis): for random small triangle soups -- random vertices, random faces, random raster
+    size, either perspective mode, the vertices squeezed towards the view so that faces overlap, interpenetrate and
+    cross the image border -- the C oracle and the independent array rasterizer give the same owner for every
+    pixel, the same barycentrics and the same depth."""
+    from hypothesis import given, settings, strategies as st
+    from oracle import raster_np
+
+    @settings(max_examples=40, deadline=None, derandomize=True)
+    @given(seed=st.integers(0, 2 ** 31 - 1), S=st.sampled_from([8, 17, 32]), persp=st.booleans(), nf=st.integers(1, 40))
+    def check(seed, S, persp, nf):
+        rng = np.random.default_rng(seed)
+        V = 24
+        scr = np.concatenate([rng.uniform(-1.3, 1.3, (V, 2)), rng.uniform(-0.5, 6.0, (V, 1))], 1).astype(np.float32)
+        scr[rng.integers(0, V)] = scr[rng.integers(0, V)]                     # a repeated vertex position now and then
+        faces = rng.integers(0, V, (nf, 3)).astype(np.int32)
+        if nf > 3:
+            faces[-1] = faces[0]                                               # an exact duplicate: ties
+        cfg = oracle.make_cfg(S, S, S, 128, 9.5, perspective_correct=persp)
+        pf, bf, zf = oracle.rasterize(cfg, scr, faces, crop=False)
+        p2, b2, z2 = raster_np.rasterize(scr, faces, S, persp, cfg.k_eps)
+        assert np.array_equal(pf, p2)
+        cov = pf >= 0
+        assert np.array_equal(bf[cov], b2[cov]) and np.array_equal(zf[cov], z2[cov])
+        assert np.all(bf[~cov] == -1) and np.all(b2[~cov] == -1)
+
+    check()
