@@ -673,6 +673,46 @@ def test_full_size_properties():
     assert np.abs(C - res.campos.cpu().numpy()).max() < 1e-4
 
 
+@pytest.mark.parametrize('mode', ['perspective_correct', 'turn_off_clutter', 'six_dof'])
+def test_full_size_other_modes_teacher_forced(oracle, mode):
+    """BASELINE size (640x800, V = 1088, 12 classes) in the modes the headline run does not use: PyTorch3D >= 0.4
+    perspective-correct barycentrics, the clutter-free loss (loss_fun0, --turn_off_clutter) and the 6-DoF solve of
+    PredUnlabeledDataset.py.  Grid-search argmin equal to the oracle's, loss and every gradient component
+    teacher-forced along the GPU's trajectory within 1e-4."""
+    from nemo_amd.pose_solver import SolverConfig
+    from nemo_amd.workloads import twelve_class_workload
+    kw = {'perspective_correct': dict(perspective_correct=True), 'turn_off_clutter': dict(turn_off_clutter=True),
+          'six_dof': dict(six_dof=True)}[mode]
+    cfg = SolverConfig(total_epochs=120, **kw)
+    wl = twelve_class_workload(6, seed=31, cfg=cfg, categories=['car', 'bicycle', 'sofa'])
+    s, eng = wl.solver, wl.solver.engine
+    res = s.solve_all(wl.feats, wl.clutter, wl.mesh_idx, want_trace=True)
+    trace, best = res.trace.cpu().numpy(), res.init_index.cpu().numpy()
+    ocfg = oracle.make_cfg(eng.S, eng.h, eng.w, eng.D, eng.ndc_scale, perspective_correct=cfg.perspective_correct,
+                           clutter=not cfg.turn_off_clutter)
+    feats, cvec, mesh = wl.feats.cpu().numpy(), wl.clutter[0].cpu().numpy(), wl.mesh_idx.cpu().numpy()
+    gC, gT = s.grid_C.cpu().numpy(), s.grid_theta.cpu().numpy()
+    meshes = [(v.cpu().numpy(), f.cpu().numpy(), b.cpu().numpy()) for v, f, b in eng._keep]
+    assert np.isfinite(trace).all()
+    for i in range(6):
+        v, f, b = meshes[mesh[i]]
+        clu = None if cfg.turn_off_clutter else oracle.clutter_score(ocfg, feats[i], cvec)
+        bo, _ = oracle.grid_search(ocfg, v, f, b, feats[i], clu, gC[mesh[i]], gT[mesh[i]])
+        assert bo == best[i]
+        for t in (0, 40, 119):
+            if mode == 'six_dof':
+                p = trace[i, t, 0:6]
+                e = oracle.evaluate(ocfg, v, f, b, feats[i], clu, p[0:3], p[3], extra=np.array([p[4], p[5], 0.0], np.float32))
+                got_l, got_g, want_g = trace[i, t, 6], trace[i, t, 7:13], np.r_[e['gC'], e['gtheta'], e['gextra'][:2]]
+            else:
+                e = oracle.evaluate(ocfg, v, f, b, feats[i], clu, trace[i, t, 0:3], trace[i, t, 3])
+                got_l, got_g, want_g = trace[i, t, 4], trace[i, t, 5:9], np.r_[e['gC'], e['gtheta']]
+            assert abs(got_l - e['loss']) <= REL * abs(e['loss'])
+            assert _relerr(got_g, want_g) <= REL
+    loss_col = 6 if mode == 'six_dof' else 4
+    assert trace[:, -1, loss_col].mean() < trace[:, 0, loss_col].mean()
+
+
 def test_solve_launch_order_is_invisible():
     """Batches of more than 64 jobs are launched longest job first (solve_cost_kernel / solve_order_kernel):
     scheduling only -- poses, losses and traces are bit-identical to the same jobs solved in small,
