@@ -46,6 +46,8 @@ def build_parser():
     p.add_argument('--feat_dim', default=128, type=int)
     p.add_argument('--six_dof', action='store_true', help='PredUnlabeledDataset.py variant; writes --save_final_pred')
     p.add_argument('--save_final_pred', default='', type=str)
+    p.add_argument('--no_reload', action='store_true',
+                   help='with --save_final_pred: solve every image again instead of keeping the entries the file already holds')
     p.add_argument('--accuracy_table', default='', type=str, help='directory of per-category records: print CalAccuracy table')
     p.add_argument('--batch', default=256, type=int, help='images per solve launch; the next batch is read and uploaded meanwhile')
     return p
@@ -150,14 +152,26 @@ def run_sharded(n_items, solve_fn, device):
     return gather_records(local.to(device), n_items)
 
 
-def solve_category(args, device='cuda:0'):
-    """-> (names, [n, 10] records of every image of the category, on the host)."""
+def load_final_pred(path):
+    """Entries of an earlier final_pred.npz (code/PredUnlabeledDataset.py:297-298), read without unpickling."""
+    with np.load(path, allow_pickle=False) as z:
+        return {k: np.asarray(z[k], dtype=np.float64) for k in z.files}
+
+
+def solve_category(args, device='cuda:0', skip=()):
+    """-> (names, mesh index per name, [n, 10] records on the host) of the category's images, those named in `skip`
+    left out (resume: code/PredUnlabeledDataset.py:301-303)."""
     cate = args.type_
     mesh_dir = args.mesh_path % (args.mesh_d, cate) if args.mesh_path.count('%s') == 2 else args.mesh_path
     n_mesh = len([f for f in os.listdir(mesh_dir) if f.endswith('.off')])
     subtypes = ['mesh%02d' % i for i in range(1, 1 + n_mesh)]                      # :172
     with records.FeatureRecord(record_path(args)) as rec:
         names, mesh_of = category_jobs(rec, subtypes)
+        if skip:
+            keep = [i for i, n in enumerate(names) if n not in skip]
+            names, mesh_of = [names[i] for i in keep], [mesh_of[i] for i in keep]
+        if not names:
+            return names, mesh_of, np.zeros((0, RECORD_WIDTH), np.float32)
         recs = run_sharded(len(names), lambda lo, hi: solve_shard(args, rec, subtypes, names[lo:hi], mesh_of[lo:hi], device)[0],
                            device)
     return names, mesh_of, recs.cpu().numpy()
@@ -186,7 +200,10 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group('nccl' if torch.cuda.is_available() else 'gloo')
-    names, _, recs = solve_category(args, 'cuda:%d' % local)
+    done = {}
+    if args.save_final_pred and not args.no_reload and os.path.exists(args.save_final_pred):  # PredUnlabeledDataset.py:297-303
+        done = load_final_pred(args.save_final_pred)
+    names, _, recs = solve_category(args, 'cuda:%d' % local, skip=set(done))
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
@@ -196,7 +213,8 @@ def main(argv=None):
     if args.save_final_pred:                                                       # PredUnlabeledDataset.py:344-352
         os.makedirs(os.path.dirname(os.path.abspath(args.save_final_pred)), exist_ok=True)
         preds = recs[:, [0, 3, 1, 2, 8, 9]]                                        # distance, theta, elevation, azimuth, t0, t1
-        np.savez(args.save_final_pred, **{n: preds[i] for i, n in enumerate(names)})
+        done.update({n: preds[i] for i, n in enumerate(names)})
+        np.savez(args.save_final_pred, **done)
     total_error, cads = errors_from_records(names, recs, anno_dir)
     if args.save_accuracy:                                                         # :273-274
         records.save_category_errors(args.save_accuracy, total_error, cads)

@@ -1136,6 +1136,20 @@ def test_solve_all_runner_from_files(tmp_path, oracle):
                            '--image_size', '256,384', '--six_dof', '--save_final_pred', pred_path]) == 0
     with np.load(pred_path) as z:
         assert sorted(z.files) == sorted(feats) and all(z[n].shape == (6,) and np.all(np.isfinite(z[n])) for n in z.files)
+        first = {n: z[n].copy() for n in z.files}
+    # resume (PredUnlabeledDataset.py:297-303): entries already in the file are kept, not solved again
+    marked = dict(first)
+    gone = sorted(marked)[1]
+    del marked[gone]
+    keep = sorted(marked)[0]
+    marked[keep] = np.full(6, 7.0)
+    np.savez(pred_path, **marked)
+    assert solve_all.main(['--type_', 'car', '--record_file', rec_path, '--mesh_path', str(mesh_dir), '--anno_path', '',
+                           '--image_size', '256,384', '--six_dof', '--save_final_pred', pred_path]) == 0
+    with np.load(pred_path) as z:
+        assert sorted(z.files) == sorted(feats)
+        assert np.array_equal(z[keep], np.full(6, 7.0))                 # untouched
+        assert np.array_equal(z[gone].astype(np.float32), first[gone].astype(np.float32))   # solved again: same result
 
 
 def test_dense_pose_grid_search(oracle):
