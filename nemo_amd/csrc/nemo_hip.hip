@@ -464,7 +464,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
 #define NEMO_KIT 2
 #endif
   constexpr int KIT = NEMO_KIT;             // 16-byte loads per row per lane
-  constexpr int LPP = D / (4 * KIT);        // lanes per pixel: 8 (D=128) or 16 (D=256)
+  constexpr int LPP = D / (4 * KIT);        // lanes per pixel: 16 (D=128) or 32 (D=256)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: everything derived from it lives in SGPRs
   const int S = P.S;
   const float Sf = (float)S;

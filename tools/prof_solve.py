@@ -19,6 +19,8 @@ ap.add_argument('--reps', type=int, default=2)
 ap.add_argument('--grid', action='store_true', help='also time the grid search')
 ap.add_argument('--sort', action='store_true', help='order the jobs by descending coverage at the initial pose (longest first)')
 ap.add_argument('--image-size', default='640,800', help='H,W of the synthetic images (feature maps are 1/8 of it)')
+ap.add_argument('--distinct-images', type=int, default=0, help='locality probe: job j reads the feature map of image j %% K (poses and meshes stay per '
+                'job, so with --lr0 the work is unchanged and only the live set of feature bytes shrinks to K maps)')
 ap.add_argument('--lr0', action='store_true', help='zero learning rate: every step re-evaluates the initial pose (fixed work for ablations)')
 args = ap.parse_args()
 wl = twelve_class_workload(args.images, seed=1000, cfg=SolverConfig(total_epochs=args.steps, image_size=tuple(int(v) for v in args.image_size.split(',')),
@@ -35,6 +37,9 @@ if args.sort:
     img_idx, mesh_idx = perm.to(torch.int32), wl.mesh_idx[perm].contiguous()
     C0, th0 = C0[perm].contiguous(), th0[perm].contiguous()
     torch.cuda.synchronize()
+if args.distinct_images > 0:
+    base = torch.arange(args.images, device=C0.device, dtype=torch.int32) if img_idx is None else img_idx
+    img_idx = (base % args.distinct_images).to(torch.int32).contiguous()
 for r in range(args.reps):
     if os.environ.get('NEMO_HIP_LIB') and hasattr(eng.lib, 'nemo_debug_stamps'):
         import ctypes
