@@ -1548,88 +1548,152 @@ __global__ __launch_bounds__(256) void grid_finish_kernel(int hw, float inv_hw, 
 // directly in the solver's pixel-major layout [N][h*w][D].
 // out[d, p] = sum_c W[d, c] x[c, p] runs on v_mfma_f32_32x32x2_f32: A = 32 output channels (D/32 tiles kept in
 // accumulators), B = 32 consecutive pixels of one image (coalesced dword loads per channel), the whole weight
-// matrix staged once per workgroup in LDS in the order the lanes consume it.  Workgroups are persistent.
+// matrix staged once per workgroup in LDS in the order the lanes consume it (one 16-byte read per k-step and four
+// output tiles).  Workgroups are persistent.  The LDS-resident weights leave room for one workgroup -- two waves
+// per SIMD -- per CU, so little but the wave's own instruction stream hides latency: the channels go through in
+// chunks of 2 * FH_KS, branch-free and fully unrolled; the B operands of the NEXT chunk (the next tile's first
+// chunk after a tile's last) are loaded into the other half of a register ping-pong one by one between the groups
+// of matrix instructions of this chunk (a whole chunk = FH_KS x 4 x 64 cycles ahead of their use), and the A
+// operands are read from LDS one k-step ahead.  Measured (tools/prof_head.py, 512 images, C = 256 -> D = 128):
+// 2.45 ms = 110 TFLOP/s, 0.70 of the fp32 matrix peak (the branchy per-k-step version it replaces: 66).
+constexpr int FH_KS = 32;  // k-steps (channel pairs) per chunk
+constexpr int FH_NT = 512, FH_NW = FH_NT / 64;  // two waves per SIMD, 256 registers each: accumulators 64 (D = 128), B ping-pong 64
 template <int D>
-__global__ __launch_bounds__(256) void feature_head_kernel(const float *__restrict__ x, int N, int C, int hw,
-                                                           const float *__restrict__ weight,
-                                                           const float *__restrict__ cbank, int K,
-                                                           float *__restrict__ feat, float *__restrict__ clu) {
-  constexpr int T = D / 32;           // output-channel tiles
-  extern __shared__ float wl[];       // [C/2][2][32][T]: (k-step, half, row in tile, tile)
+__global__ __launch_bounds__(FH_NT) void feature_head_kernel(const float *__restrict__ x, int N, int C, int hw,
+                                                             const float *__restrict__ weight,
+                                                             const float *__restrict__ cbank, int K,
+                                                             float *__restrict__ feat, float *__restrict__ clu) {
+  constexpr int T = D / 32;                        // output-channel tiles
+  extern __shared__ __align__(16) float wl[];      // [ceil(C/2 / FH_KS) * FH_KS][2][32][T]: (k-step, half, row in tile, tile); zero past C
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, half = lane >> 5;
-  for (int k = tid; k < D * C; k += 256) {
-    const int d = k / C, c = k - d * C;
-    wl[(((c >> 1) * 2 + (c & 1)) * 32 + (d & 31)) * T + (d >> 5)] = weight[k];
+  const int nch = (C / 2 + FH_KS - 1) / FH_KS;     // chunks per tile
+  for (int k = tid; k < nch * FH_KS * 2 * D; k += FH_NT) {
+    // k = ((s * 2 + h) * 32 + r) * T + t  ->  weight[d = 32 t + r][c = 2 s + h]
+    const int t = k % T, r = (k / T) & 31, h = (k / (32 * T)) & 1, s2 = k / (64 * T);
+    const int c = 2 * s2 + h;
+    wl[k] = c < C ? weight[(size_t)(32 * t + r) * C + c] : 0.0f;
   }
   __syncthreads();
   const int tiles_per_img = (hw + 31) / 32;
   const long long total = (long long)N * tiles_per_img;
-  // The LDS-resident weights leave room for one workgroup (one wave per SIMD) per CU, so each wave has the
-  // whole register file: the B operand of a tile (one float per k-step) is fetched a full tile ahead.
-  constexpr int KS = 128;  // k-steps held in registers (C <= 256)
-  float bcur[KS], bnxt[KS];
-  auto fetch = [&](long long tile, float (&b)[KS]) {
+  const size_t hw2 = 2 * (size_t)hw;
+  // address of this lane's B value of k-step 0 of chunk `ch` of tile `tile`: channel 2 (ch FH_KS) + half of pixel p0 + i
+  auto b_ptr = [&](long long tile, int ch) {
     const int n = (int)(tile / tiles_per_img), p0 = (int)(tile - (long long)n * tiles_per_img) * 32;
-    const float *xp = x + ((size_t)n * C + half) * hw + min(p0 + i, hw - 1);  // channel 2s + half of the lane's pixel
-#pragma unroll
-    for (int s2 = 0; s2 < KS; ++s2) b[s2] = s2 < C / 2 ? __builtin_nontemporal_load(xp + (size_t)(2 * s2) * hw) : 0.0f;
+    return x + ((size_t)n * C + half + 2 * ch * FH_KS) * hw + min(p0 + i, hw - 1);
   };
-  long long tile = (long long)blockIdx.x * 4 + wave;
-  const long long stride = (long long)gridDim.x * 4;
-  if (tile < total) fetch(tile, bcur);
-  for (; tile < total; tile += stride) {
-    const int n = (int)(tile / tiles_per_img), p0 = (int)(tile - (long long)n * tiles_per_img) * 32;
-    const int p = min(p0 + i, hw - 1);
-    const bool pok = p0 + i < hw;
-    if (tile + stride < total) fetch(tile + stride, bnxt);
-    f16v acc[T];
+  const long long stride = (long long)gridDim.x * FH_NW;
+  long long tile = (long long)blockIdx.x * FH_NW + wave;
+  if (tile >= total) return;
+  int ch = 0;
+  f16v acc[T];
+  float b0[FH_KS], b1[FH_KS];
+  {
+    const float *xq = b_ptr(tile, 0);
+    const int nv = min(FH_KS, C / 2);
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+    for (int s2 = 0; s2 < FH_KS; ++s2) {
+      b0[s2] = __builtin_nontemporal_load(xq);
+      xq += s2 + 1 < nv ? hw2 : 0;
+    }
+  }
+  // one chunk: FH_KS k-steps on `bc` with the next chunk's B values fetched into `bn` between them, and the tile's
+  // epilogue after its last chunk
+  auto chunk = [&](float (&bc)[FH_KS], float (&bn)[FH_KS]) {
+    const bool last_ch = ch + 1 == nch;
+    const long long ntile = last_ch ? tile + stride : tile;
+    const int nchk = last_ch ? 0 : ch + 1;
+    // source of the prefetch; after the wave's last chunk: a harmless re-read of the chunk in hand.  Past C / 2 the
+    // last channel pair of the SAME pixel is re-read and meets zero weights (no select on the loaded value: it
+    // would make the wave wait for the load here instead of a chunk later).
+    const bool more = ntile < total;
+    const float *xq = b_ptr(more ? ntile : tile, more ? nchk : ch);
+    const int nv = min(FH_KS, C / 2 - (more ? nchk : ch) * FH_KS);
+    if (ch == 0) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+      for (int t = 0; t < T; ++t)
 #pragma unroll
-    for (int s2 = 0; s2 < KS; ++s2) {
-      if (s2 < C / 2) {
-        const float *wp = wl + ((s2 * 2 + half) * 32 + i) * T;
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    }
+    const float *wp = wl + (size_t)(((ch * FH_KS) * 2 + half) * 32 + i) * T;
+    // A operands run one k-step ahead of the matrix instructions that use them (few waves per SIMD: an LDS read
+    // issued behind a group of matrix instructions would only start when the last of them issues)
+    f4 ae[T / 4], ao[T / 4];  // even / odd k-steps: two live register sets, so a read can be issued a step early
+    auto lds_a = [&](int s2, f4(&a)[T / 4]) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[t], bcur[s2], acc[t], 0, 0, 0);
+      for (int t4 = 0; t4 < T / 4; ++t4) a[t4] = *(const f4 *)(wp + s2 * 64 * T + 4 * t4);
+    };
+    auto mfma_step = [&](const f4(&a)[T / 4], float bv) {
+#pragma unroll
+      for (int t4 = 0; t4 < T / 4; ++t4) {
+        acc[4 * t4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t4].x, bv, acc[4 * t4], 0, 0, 0);
+        acc[4 * t4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t4].y, bv, acc[4 * t4 + 1], 0, 0, 0);
+        acc[4 * t4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t4].z, bv, acc[4 * t4 + 2], 0, 0, 0);
+        acc[4 * t4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t4].w, bv, acc[4 * t4 + 3], 0, 0, 0);
+      }
+    };
+    lds_a(0, ae);
+#pragma unroll
+    for (int s2 = 0; s2 < FH_KS; s2 += 2) {
+      // full scheduling fences: left alone, the scheduler sinks each read to just above the instructions that use it
+      lds_a(s2 + 1, ao);
+      bn[s2] = __builtin_nontemporal_load(xq);
+      xq += s2 + 1 < nv ? hw2 : 0;
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(ae, bc[s2]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s2 + 2 < FH_KS) lds_a(s2 + 2, ae);
+      bn[s2 + 1] = __builtin_nontemporal_load(xq);
+      xq += s2 + 2 < nv ? hw2 : 0;
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(ao, bc[s2 + 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (last_ch) {
+      const int n = (int)(tile / tiles_per_img), p0 = (int)(tile - (long long)n * tiles_per_img) * 32;
+      const int p = min(p0 + i, hw - 1);
+      const bool pok = p0 + i < hw;
+      // lane (pixel j = i, half) holds channels d = 32 t + 8 q + 4 half + c, q, c = 0..3  (acc[t][4 q + c])
+      float n2 = 0.0f;
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) n2 = fmaf(acc[t][r], acc[t][r], n2);
+      n2 += __shfl_xor(n2, 32);
+      const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);  // F.normalize(p=2, dim=1, eps=1e-12)
+      float *op = feat + ((size_t)n * hw + p) * D + 4 * half;
+      float best = -INFINITY;
+      for (int k = 0; k < (clu ? K : 0); ++k) {
+        const float *ck = cbank + (size_t)k * D + 4 * half;
+        float dsum = 0.0f;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f4 cv = *(const f4 *)(ck + 32 * t + 8 * q);
+            dsum = fmaf(acc[t][4 * q] * inv, cv.x, dsum); dsum = fmaf(acc[t][4 * q + 1] * inv, cv.y, dsum);
+            dsum = fmaf(acc[t][4 * q + 2] * inv, cv.z, dsum); dsum = fmaf(acc[t][4 * q + 3] * inv, cv.w, dsum);
+          }
+        dsum += __shfl_xor(dsum, 32);
+        best = fmaxf(best, dsum);
+      }
+      if (pok) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *(f4 *)(op + 32 * t + 8 * q) = f4{acc[t][4 * q] * inv, acc[t][4 * q + 1] * inv, acc[t][4 * q + 2] * inv, acc[t][4 * q + 3] * inv};
+        if (clu && half == 0) clu[(size_t)n * hw + p] = best;
       }
     }
-#pragma unroll
-    for (int s2 = 0; s2 < KS; ++s2) bcur[s2] = bnxt[s2];
-    // lane (pixel j = i, half) holds channels d = 32 t + 8 q + 4 half + c, q, c = 0..3  (acc[t][4 q + c])
-    float n2 = 0.0f;
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) n2 = fmaf(acc[t][r], acc[t][r], n2);
-    n2 += __shfl_xor(n2, 32);
-    const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);  // F.normalize(p=2, dim=1, eps=1e-12)
-    float *op = feat + ((size_t)n * hw + p) * D + 4 * half;
-    float best = -INFINITY;
-    for (int k = 0; k < (clu ? K : 0); ++k) {
-      const float *ck = cbank + (size_t)k * D + 4 * half;
-      float dsum = 0.0f;
-#pragma unroll
-      for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f4 cv = *(const f4 *)(ck + 32 * t + 8 * q);
-          dsum = fmaf(acc[t][4 * q] * inv, cv.x, dsum); dsum = fmaf(acc[t][4 * q + 1] * inv, cv.y, dsum);
-          dsum = fmaf(acc[t][4 * q + 2] * inv, cv.z, dsum); dsum = fmaf(acc[t][4 * q + 3] * inv, cv.w, dsum);
-        }
-      dsum += __shfl_xor(dsum, 32);
-      best = fmaxf(best, dsum);
-    }
-    if (pok) {
-#pragma unroll
-      for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *(f4 *)(op + 32 * t + 8 * q) = f4{acc[t][4 * q] * inv, acc[t][4 * q + 1] * inv, acc[t][4 * q + 2] * inv, acc[t][4 * q + 3] * inv};
-      if (clu && half == 0) clu[(size_t)n * hw + p] = best;
-    }
+    tile = ntile;
+    ch = nchk;
+  };
+  while (tile < total) {
+    chunk(b0, b1);
+    if (tile >= total) break;
+    chunk(b1, b0);
   }
 }
 
@@ -2769,17 +2833,18 @@ int nemo_feature_head(nemo_ctx *ctx, const float *d_x, int32_t N, int32_t C, con
   if (!d_x || !d_weight || !d_feat) return fail(ctx, NEMO_ERR_ARG, "nemo_feature_head: null buffer");
   if (d_clu && (!d_cbank || K <= 0)) return fail(ctx, NEMO_ERR_ARG, "nemo_feature_head: clutter output needs a clutter bank");
   const int D = ctx->cfg.feat_dim, hw = ctx->cfg.win_h * ctx->cfg.win_w;
-  const size_t lds = (size_t)D * C * sizeof(float);
+  // the weights are LDS-resident, padded with zeros to whole chunks of 2 * FH_KS channels
+  const size_t lds = (size_t)D * 2 * FH_KS * ((C / 2 + FH_KS - 1) / FH_KS) * sizeof(float);
   if ((C & 1) || lds > 128 * 1024)
-    return fail(ctx, NEMO_ERR_UNSUPPORTED, "nemo_feature_head: C = %d (even, D*C*4 <= 128 KiB: the weights are LDS-resident)", C);
+    return fail(ctx, NEMO_ERR_UNSUPPORTED, "nemo_feature_head: C = %d (even; D * C * 4 <= 128 KiB after rounding C up to a multiple of %d: the weights are LDS-resident)", C, 2 * FH_KS);
   const int n_cu = ctx->n_cu;  // cached by nemo_ctx_create, which also opted the kernel in to 128 KiB of LDS
   const long long tiles = (long long)N * ((hw + 31) / 32);
-  const unsigned blocks = (unsigned)(tiles / 4 < n_cu ? (tiles + 3) / 4 : n_cu);
+  const unsigned blocks = (unsigned)(tiles / FH_NW < n_cu ? (tiles + FH_NW - 1) / FH_NW : n_cu);
   if (D == 128) {
-    hipLaunchKernelGGL((feature_head_kernel<128>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, d_x, N, C, hw, d_weight,
+    hipLaunchKernelGGL((feature_head_kernel<128>), dim3(blocks), dim3(FH_NT), lds, (hipStream_t)stream, d_x, N, C, hw, d_weight,
                        d_cbank, K, d_feat, d_clu);
   } else {
-    hipLaunchKernelGGL((feature_head_kernel<256>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, d_x, N, C, hw, d_weight,
+    hipLaunchKernelGGL((feature_head_kernel<256>), dim3(blocks), dim3(FH_NT), lds, (hipStream_t)stream, d_x, N, C, hw, d_weight,
                        d_cbank, K, d_feat, d_clu);
   }
   HIP_TRY(ctx, hipGetLastError());

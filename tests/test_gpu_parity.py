@@ -1283,7 +1283,7 @@ def test_loss_landscape_scans(oracle):
             assert int(np.argmin(scans[k][i])) == len(scans[k][i]) // 2   # zero shift is the minimum
 
 
-@pytest.mark.parametrize('D,Cin', [(128, 256), (256, 64)])
+@pytest.mark.parametrize('D,Cin', [(128, 256), (256, 64), (128, 96), (128, 6), (256, 128)])
 def test_feature_head_matches_torch(D, Cin):
     """Backbone tail (code/models/KeypointRepresentationNet.py:217-223: 1x1 conv with out_layer.weight, then
     F.normalize over channels) fused with the clutter score (code/MeshPoseSolveAll.py:220), against the same ops
@@ -1307,3 +1307,24 @@ def test_feature_head_matches_torch(D, Cin):
     assert none is None and torch.equal(feat2, feat)
     # the fused clutter score equals the standalone kernel's on the produced features
     assert (eng.clutter_score(feat, cb) - clu).abs().max().item() <= 2e-6
+
+
+def test_feature_head_persistent_waves():
+    """More 32-pixel tiles than the launch has waves (one workgroup of 8 waves per CU), so waves walk on to further
+    tiles with the next tile's operands prefetched under the current one; a non-multiple-of-64 channel count makes the
+    last chunk of every tile partial."""
+    import torch.nn.functional as F
+    from nemo_amd.engine import PoseEngine
+    h, w, N, D, Cin = 32, 41, 72, 128, 160
+    eng = PoseEngine(48, (h, w), D)
+    g = torch.Generator(device='cpu').manual_seed(6)
+    x = torch.randn(N, Cin, h, w, generator=g).cuda()
+    W = (torch.randn(D, Cin, generator=g) / Cin ** 0.5).cuda()
+    cb = F.normalize(torch.randn(2, D, generator=g), dim=1).cuda()
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    assert N * ((h * w + 31) // 32) > 8 * n_cu
+    feat, clu = eng.feature_head(x, W, cb)
+    ref = F.normalize(F.conv2d(x, W[:, :, None, None]), p=2, dim=1)
+    ref_clu = F.conv2d(ref, cb[:, :, None, None]).max(dim=1)[0]
+    assert (feat - ref.permute(0, 2, 3, 1)).abs().max().item() <= 2e-6
+    assert (clu - ref_clu).abs().max().item() <= 5e-6

@@ -9,10 +9,12 @@ h, w, C, D = 80, 100, 256, 128
 eng = PoseEngine(100, (h, w), D)
 x = torch.randn(args.images, C, h, w, device='cuda'); W = torch.randn(D, C, device='cuda') / 16
 cb = torch.nn.functional.normalize(torch.randn(1, D, device='cuda'), dim=1)
+eng.feature_head(x, W, cb)
 for r in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    eng.feature_head(x, W, cb)
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    for _ in range(10):
+        eng.feature_head(x, W, cb)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
     fl = 2.0 * args.images * h * w * C * D
     by = args.images * h * w * (C + D + 1) * 4.0
     print(f'feature_head: {args.images} images {dt*1e3:.2f} ms  {fl/dt/1e12:.1f} TFLOP/s  {by/dt/1e9:.0f} GB/s')
