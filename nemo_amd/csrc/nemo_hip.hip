@@ -1947,44 +1947,123 @@ __global__ __launch_bounds__(NT, 4) void interp_bwd_kernel(KParams P, const Mesh
 // Clutter score: out[p] = max_k <cbank[k], feat[p]> (code/MeshPoseSolveAll.py:220,
 // lib/MeshUtils.py:273-275) on the fp32 MFMA (v_mfma_f32_32x32x2_f32, exact f32
 // fmaf chain).  A = 32 clutter vectors, B = 32 pixels, so a lane owns one pixel
-// column and the max over clutter vectors is a max over its 16 accumulators.
+// column and the max over clutter vectors is a max over its accumulators.
 // Lane (i = l & 31, half = l >> 5) feeds feature index 8q + 4*half + c as k-step
-// 4q + c: both operands are then plain 16-byte loads.
+// 4q + c: both operands are then plain 16-byte reads.
+// Persistent workgroups.  The bank goes through LDS in chunks of CK_ROWS vectors (rows padded by four floats: the
+// 16-byte reads of a wave are conflict-free), double-buffered when there is more than one chunk, so the A operand
+// never shares the in-order vector-memory counter with the feature rows; every wave keeps the 32 feature rows of
+// its tile in registers and fetches the rows of its NEXT tile into a second register set under the matrix
+// instructions of the last chunk (without it the waves of a SIMD load together and multiply together: time =
+// stream time + matrix time, 65 TFLOP/s at K = 64; now 104, and 141 = 0.90 of the fp32 matrix peak at K = 2560,
+// tools/time_clutter.py).  Rows past K repeat row K - 1, which leaves the max alone.
+constexpr int CK_ROWS = 64;
+template <int D> struct CkCfg { static constexpr int NT = D <= 128 ? 512 : 256; };  // registers per wave: 256 / 512
 template <int D>
-__global__ __launch_bounds__(256) void clutter_kernel(const float *__restrict__ feat, size_t npix,
-                                                      const float *__restrict__ cbank, int K,
-                                                      float *__restrict__ out) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__global__ __launch_bounds__(CkCfg<D>::NT) void clutter_kernel(const float *__restrict__ feat, size_t npix,
+                                                               const float *__restrict__ cbank, int K,
+                                                               float *__restrict__ out) {
+  constexpr int NT = CkCfg<D>::NT, NWV = NT / 64;
+  constexpr int RS = D + 4;                       // padded row stride in floats
+  constexpr int NS = CK_ROWS * (D / 4) / NT;      // 16-byte pieces of a chunk per thread
+  extern __shared__ __align__(16) float cl[];     // [2][CK_ROWS][RS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, half = lane >> 5;
-  const size_t pix0 = ((size_t)blockIdx.x * 4 + wave) * 32;
-  if (pix0 >= npix) return;
-  const size_t pix = pix0 + i < npix ? pix0 + i : npix - 1;
-  const f4 *xp = (const f4 *)(feat + pix * D) + half;
-  f4 x[D / 8];
+  const int nchunks = (K + CK_ROWS - 1) / CK_ROWS;
+  const size_t ntiles = (npix + 31) / 32;
+  f4 st[NS];
+  auto stage_load = [&](int c) {
 #pragma unroll
-  for (int q = 0; q < D / 8; ++q) x[q] = __builtin_nontemporal_load(xp + 2 * q);
-  float best = -INFINITY;
-  for (int k0 = 0; k0 < K; k0 += 32) {
-    const int kr = k0 + i < K ? k0 + i : K - 1;
-    const f4 *cp = (const f4 *)(cbank + (size_t)kr * D) + half;
-    f16v acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < D / 8; ++q) {
-      const f4 c = cp[2 * q];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(c.x, x[q].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(c.y, x[q].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(c.z, x[q].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(c.w, x[q].w, acc, 0, 0, 0);
+    for (int j = 0; j < NS; ++j) {
+      const int idx = tid + j * NT, row = idx / (D / 4), col4 = idx - row * (D / 4);
+      st[j] = ((const f4 *)cbank)[(size_t)min(c * CK_ROWS + row, K - 1) * (D / 4) + col4];
     }
-    // C/D layout: column = lane & 31 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * half (clutter vector)
+  };
+  auto stage_store = [&](int buf) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (row < K) best = fmaxf(best, acc[r]);
+    for (int j = 0; j < NS; ++j) {
+      const int idx = tid + j * NT, row = idx / (D / 4), col4 = idx - row * (D / 4);
+      *(f4 *)(cl + (size_t)buf * CK_ROWS * RS + row * RS + 4 * col4) = st[j];
     }
+  };
+  auto load_x = [&](size_t tile, f4(&x)[D / 8]) {
+    const size_t pix = min(tile * 32 + (size_t)i, npix - 1);
+    const f4 *xp = (const f4 *)(feat + pix * D) + half;
+#pragma unroll
+    for (int q = 0; q < D / 8; ++q) x[q] = __builtin_nontemporal_load(xp + 2 * q);
+  };
+  const size_t stride = (size_t)gridDim.x * NWV;
+  size_t base = (size_t)blockIdx.x * NWV;  // the workgroup's first tile of the round; every wave takes part in every
+  if (base >= ntiles) return;              // round (barriers), waves past the end recompute the last tile and write nothing
+  f4 xa[D / 8], xb[D / 8];
+  stage_load(0);
+  load_x(min(base + wave, ntiles - 1), xa);
+  stage_store(0);
+  __syncthreads();
+  int buf = 0;
+  auto round = [&](f4(&xc)[D / 8], f4(&xn)[D / 8]) {
+    const size_t tile = base + wave;
+    const size_t nbase = base + stride;
+    float best = -INFINITY;
+    for (int c = 0; c < nchunks; ++c) {
+      if (c + 1 == nchunks) load_x(min((nbase < ntiles ? nbase : base) + wave, ntiles - 1), xn);
+      if (nchunks > 1) stage_load(c + 1 == nchunks ? 0 : c + 1);
+      const float *ap = cl + (size_t)buf * CK_ROWS * RS + i * RS + 4 * half;
+      // rows i (and, when the chunk holds more than 32 vectors, 32 + i) of the chunk against the tile's 32 pixels;
+      // the A operands are read one step ahead of the matrix instructions that use them
+      auto contract = [&](auto two_tag) {
+        constexpr bool TWO = decltype(two_tag)::value;
+        f16v acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+        f4 e0, e1, o0, o1;
+        e0 = *(const f4 *)(ap);
+        if (TWO) e1 = *(const f4 *)(ap + 32 * RS);
+        auto mm = [&](const f4 &a0, const f4 &a1, const f4 &xv) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, xv.x, acc0, 0, 0, 0);
+          if (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, xv.x, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, xv.y, acc0, 0, 0, 0);
+          if (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, xv.y, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, xv.z, acc0, 0, 0, 0);
+          if (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, xv.z, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, xv.w, acc0, 0, 0, 0);
+          if (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, xv.w, acc1, 0, 0, 0);
+        };
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < D / 8; q += 2) {
+          o0 = *(const f4 *)(ap + 8 * (q + 1));
+          if (TWO) o1 = *(const f4 *)(ap + 32 * RS + 8 * (q + 1));
+          __builtin_amdgcn_sched_barrier(0);
+          mm(e0, e1, xc[q]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (q + 2 < D / 8) {
+            e0 = *(const f4 *)(ap + 8 * (q + 2));
+            if (TWO) e1 = *(const f4 *)(ap + 32 * RS + 8 * (q + 2));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          mm(o0, o1, xc[q + 1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) best = fmaxf(best, TWO ? fmaxf(acc0[r], acc1[r]) : acc0[r]);
+      };
+      if (K - c * CK_ROWS > 32) contract(std::true_type{}); else contract(std::false_type{});
+      if (nchunks > 1) {
+        stage_store(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+      }
+    }
+    best = fmaxf(best, __shfl_xor(best, 32));
+    if (half == 0 && tile < ntiles && tile * 32 + i < npix) out[tile * 32 + i] = best;
+    base = nbase;
+  };
+  while (base < ntiles) {
+    round(xa, xb);
+    if (base >= ntiles) break;
+    round(xb, xa);
   }
-  best = fmaxf(best, __shfl_xor(best, 32));
-  if (half == 0 && pix0 + i < npix) out[pix0 + i] = best;
 }
 
 // Clutter score for a small bank (K <= 8; the reference's mean clutter vector is K = 1, code/MeshPoseSolveAll.py:207):
@@ -2327,6 +2406,8 @@ int nemo_ctx_create(const nemo_config *cfg, nemo_ctx **out) {
 #undef SET_LDS
   hipFuncSetAttribute((const void *)feature_head_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
   hipFuncSetAttribute((const void *)feature_head_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  hipFuncSetAttribute((const void *)clutter_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CK_ROWS * (128 + 4) * 4);
+  hipFuncSetAttribute((const void *)clutter_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CK_ROWS * (256 + 4) * 4);
   // device facts and environment switches are read here, once; hot calls never query either
   ctx->n_cu = 256;
   {
@@ -2817,10 +2898,18 @@ int nemo_clutter_score(nemo_ctx *ctx, const float *d_feat, int32_t n_img, const 
     HIP_TRY(ctx, hipGetLastError());
     return NEMO_OK;
   }
-  if (ctx->cfg.feat_dim == 128)
-    hipLaunchKernelGGL((clutter_kernel<128>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_feat, npix, d_cbank, K, d_out);
-  else
-    hipLaunchKernelGGL((clutter_kernel<256>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_feat, npix, d_cbank, K, d_out);
+  {
+    // persistent workgroups, one per CU; LDS = two chunks of CK_ROWS padded bank rows (the kernels were opted in to
+    // this much dynamic LDS by nemo_ctx_create)
+    const int D = ctx->cfg.feat_dim, nt = D == 128 ? CkCfg<128>::NT : CkCfg<256>::NT;
+    const size_t tiles = (npix + 31) / 32, per = (size_t)(nt / 64);
+    const unsigned nb = (unsigned)std::min<size_t>((tiles + per - 1) / per, (size_t)ctx->n_cu);
+    const size_t lds = 2 * (size_t)CK_ROWS * (D + 4) * sizeof(float);
+    if (D == 128)
+      hipLaunchKernelGGL((clutter_kernel<128>), dim3(nb), dim3(nt), lds, (hipStream_t)stream, d_feat, npix, d_cbank, K, d_out);
+    else
+      hipLaunchKernelGGL((clutter_kernel<256>), dim3(nb), dim3(nt), lds, (hipStream_t)stream, d_feat, npix, d_cbank, K, d_out);
+  }
   HIP_TRY(ctx, hipGetLastError());
   return NEMO_OK;
 }

@@ -191,8 +191,10 @@ def test_interpolate_bit_exact(oracle):
         assert np.array_equal(out[i], ref)
 
 
-@pytest.mark.parametrize('K', [1, 5, 70])
+@pytest.mark.parametrize('K', [1, 5, 9, 32, 40, 70, 129])
 def test_clutter_score(oracle, K):
+    """K <= 8: streaming dot products; above: matrix cores, the bank staged through LDS in chunks of 64 vectors (K = 9, 32:
+    one 32-row tile; 40: two; 70: a second, partial chunk; 129: three chunks, the last with one vector)."""
     sc = make_scene(n_img=2)
     eng = _engine(sc)
     rng = np.random.default_rng(4)
@@ -203,7 +205,7 @@ def test_clutter_score(oracle, K):
         assert np.abs(out[i] - ref).max() <= 2e-6  # fp32 fmaf chain vs double accumulation, |x| <= 1
 
 
-@pytest.mark.parametrize('K', [1, 64, 2560])
+@pytest.mark.parametrize('K', [1, 24, 64, 2560])
 def test_clutter_score_256d_double_resolution(oracle, K):
     """BASELINE config 5's clutter half: K-vector bank, max over K (lib/MeshUtils.py:273-275), D = 256 on the
     160 x 200 map -- clutter_kernel<256> on the matrix cores (K > 8; K = 2560 is the reference's full bank,
