@@ -130,6 +130,17 @@ def from_files_leg(n_images, dev, batch):
         torch.cuda.synchronize(dev)
         h2d_gbs = 3 * stage.numel() * 4 / (a.elapsed_time(b) * 1e-3) / 1e9
         del dst, stage
+        # (b2) what the runner does per batch, on an idle GPU: file -> pinned -> device, double-buffered, + one transpose
+        with records.FeatureRecord(rec_path) as rec:
+            nb = min(batch, n_images)
+            for _ in range(2):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                up = rec.upload_pixel_major(names[:nb], dev)
+                torch.cuda.synchronize(dev)
+                t_up = time.perf_counter() - t0
+            file_gbs = up.numel() * 4 / t_up / 1e9
+            del up
         # (c) end to end through the runner (second run: libraries and the page cache are warm, like a second category)
         args = solve_all.build_parser().parse_args(['--type_', 'car', '--record_file', rec_path, '--mesh_path',
                                                     os.path.join(d, 'cad'), '--anno_path', '', '--batch', str(batch),
@@ -142,10 +153,12 @@ def from_files_leg(n_images, dev, batch):
             dt = time.perf_counter() - t0
         ok = float(np.isfinite(recs[:, :5]).all(axis=1).mean())
         return {'images': n_images, 'record_bytes': nbytes, 'solves_per_s': n_images / dt, 'seconds': dt, 'batch': batch,
-                'host_read_gbs': read_gbs, 'h2d_gbs': h2d_gbs, 'finite_fraction': ok, 'record_write_s': t_write,
+                'host_read_gbs': read_gbs, 'h2d_gbs': h2d_gbs, 'file_to_device_gbs': file_gbs, 'finite_fraction': ok, 'record_write_s': t_write,
                 'note': 'python -m nemo_amd.solve_all path on one synthetic category (car): uncompressed feature .npz on '
-                        + ('/dev/shm' if base else 'the temp directory') + ', maps read with pread into pinned memory by up to 16 threads, '
-                        'uploaded on a side stream and transposed to pixel-major on the GPU while the previous batch is solved; '
+                        + ('/dev/shm' if base else 'the temp directory') + ', maps read with pread into pinned memory by up to 16 threads '
+                        '(host_read_gbs: first, cold pass), copied to the device by DMA on a side stream (h2d_gbs) and transposed to '
+                        'pixel-major once per batch (file_to_device_gbs: the three together, warm), on a helper thread while the '
+                        'previous batch is solved; '
                         'includes mesh registration and the grid pre-render of the category; never part of `value`'}
     finally:
         shutil.rmtree(d, ignore_errors=True)
@@ -189,7 +202,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--images', type=int, default=1024, help='images per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--from-files-images', type=int, default=512, help='images in the file-driven leg (0 = skip it)')
+    ap.add_argument('--from-files-images', type=int, default=1024, help='images in the file-driven leg (0 = skip it)')
     ap.add_argument('--from-files-batch', type=int, default=256)
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='process-group backend for N > 1: nccl = RCCL over xGMI (the product path); gloo = rehearsal of the '

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import os
 import struct
+import time
 import zipfile
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
@@ -129,16 +130,21 @@ class FeatureRecord:
     def upload_pixel_major(self, names: Sequence[str], device, chunk: int = 64, workers: int = 0,
                            stats: Optional[dict] = None) -> torch.Tensor:
         """Features of `names` as ONE [N, h, w, D] f32 device tensor (the kernels' layout).  Double-buffered: while
-        chunk k goes host -> device (pinned memory, asynchronous copy on the CURRENT stream) and is transposed to
-        pixel-major on the GPU, `workers` host threads read chunk k + 1 straight from the file into the other pinned
-        buffer.  The host never holds a transposed copy.  stats (optional dict) receives decode / wait times."""
-        import time
+        chunk k goes host -> device (pinned memory, asynchronous copy on the CURRENT stream), `workers` host threads
+        read chunk k + 1 straight from the file into the other pinned buffer.  On a GPU the chunks land in a [N, D, h, w]
+        device buffer and ONE transpose to pixel-major follows the last copy: nothing but DMA copies is queued while
+        the maps come in, because a kernel queued behind a running solve (whose workgroups fill every CU's register
+        file) would not start before that solve ends and would hold its pinned buffer until then -- pinned copies are
+        not slowed by a running solve (57 GB/s either way), whereas copies from pageable memory, a mapping of the
+        file included, drop from 41-48 to 7.6 GB/s under one (tools/from_files_breakdown.py).  The host never holds
+        a transposed copy.  stats (optional dict) receives read / wait times and the byte count."""
         if workers <= 0:
             workers = min(16, os.cpu_count() or 1)  # reader threads (a GPU box gives a job 16 CPUs)
         D, h, w = self.feature_shape(names[0])
         dev = torch.device(device)
-        out = torch.empty((len(names), h, w, D), dtype=torch.float32, device=dev)
         pin = dev.type == 'cuda'
+        # GPU: file order [N, D, h, w] first, transposed once at the end; CPU: transposed chunk by chunk
+        out = torch.empty((len(names), D, h, w) if pin else (len(names), h, w, D), dtype=torch.float32, device=dev)
         n_stage = min(chunk, len(names))
         stages = [torch.empty((n_stage, D, h, w), dtype=torch.float32, pin_memory=pin) for _ in range(2 if len(names) > chunk else 1)]
         views = [st.numpy() for st in stages]
@@ -167,10 +173,12 @@ class FeatureRecord:
                 t0 = time.perf_counter()
                 fill(k, part)
                 t_decode += time.perf_counter() - t0
-                out[s:s + len(part)] = stages[k][:len(part)].to(dev, non_blocking=pin).permute(0, 2, 3, 1)
                 if pin:
+                    out[s:s + len(part)].copy_(stages[k][:len(part)], non_blocking=True)
                     free_ev[k] = torch.cuda.Event()
                     free_ev[k].record(torch.cuda.current_stream(dev))
+                else:
+                    out[s:s + len(part)] = stages[k][:len(part)].permute(0, 2, 3, 1)
         finally:
             pool.shutdown()
             for fd in fds:
@@ -178,7 +186,7 @@ class FeatureRecord:
         if stats is not None:
             stats.update(decode_s=stats.get('decode_s', 0.0) + t_decode, stage_wait_s=stats.get('stage_wait_s', 0.0) + t_wait,
                          bytes=stats.get('bytes', 0) + len(names) * D * h * w * 4)
-        return out
+        return out.permute(0, 2, 3, 1).contiguous() if pin else out
 
 
 def write_feature_record(path: str, memory: Dict[str, np.ndarray], clutter: Dict[str, np.ndarray],

@@ -98,12 +98,14 @@ def solve_shard(args, rec, subtypes, names, mesh_of, device, stats=None):
     """Clutter score (per subtype) -> grid init -> fused solve for the listed images: [len(names), 10] records.
 
     The images go through in batches of --batch: while batch k is solved, a helper thread reads batch k + 1 from
-    the record into pinned memory and uploads it on a side stream (records.upload_pixel_major), so the file path
-    costs max(read + upload, solve) per batch instead of their sum.  Batches do not change results (every job is
-    independent)."""
+    the record into pinned memory and uploads it on a side stream (records.upload_pixel_major; DMA copies only, the
+    one transpose kernel of a batch runs when the solve before it has left the CUs), so the file path costs
+    max(read + upload, solve) per batch instead of their sum; the first batch comes in under mesh registration and
+    the grid pre-render.  Batches do not change results (every job is independent)."""
     from concurrent.futures import ThreadPoolExecutor
-    solver, clutter = build_solver(args, rec, subtypes, device)
-    dev = solver.device
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
     n, B = len(names), max(1, int(getattr(args, 'batch', 256) or 256))
     side = torch.cuda.Stream(dev)
 
@@ -115,11 +117,12 @@ def solve_shard(args, rec, subtypes, names, mesh_of, device, stats=None):
             ready.record(side)
         return feats, ready
 
-    solver.engine.reserve(min(B, n), int(solver.grid_theta.shape[1]))
-    solver.prerender()
     out, clus, inits = [], [], []
     with ThreadPoolExecutor(max_workers=1) as helper:
-        nxt = helper.submit(load, 0, min(B, n))
+        nxt = helper.submit(load, 0, min(B, n))  # the first batch comes in while the meshes are registered and pre-rendered
+        solver, clutter = build_solver(args, rec, subtypes, dev)
+        solver.engine.reserve(min(B, n), int(solver.grid_theta.shape[1]))
+        solver.prerender()
         for lo in range(0, n, B):
             hi = min(lo + B, n)
             feats, ready = nxt.result()

@@ -1330,3 +1330,26 @@ def test_feature_head_persistent_waves():
     ref_clu = F.conv2d(ref, cb[:, :, None, None]).max(dim=1)[0]
     assert (feat - ref.permute(0, 2, 3, 1)).abs().max().item() <= 2e-6
     assert (clu - ref_clu).abs().max().item() <= 5e-6
+
+
+def test_record_upload_chunks_and_transpose(tmp_path):
+    """records.upload_pixel_major on the GPU (pinned double buffer, DMA copies, one transpose at the end) returns the
+    stored maps, pixel-major, for chunk sizes that do and do not divide the count and for a single map."""
+    from nemo_amd import records
+    rng = np.random.default_rng(3)
+    D, h, w, n = 128, 9, 11, 13
+    names = ['im_%02d' % i for i in range(n)]
+    maps = {k: rng.standard_normal((D, h, w)).astype(np.float32) for k in names}
+    path = str(tmp_path / 'rec.npz')
+    records.write_feature_record(path, {'mesh01': np.zeros((4, D), np.float32)}, {'mesh01': np.zeros((2, D), np.float32)},
+                                 {'mesh01': names}, maps)
+    with records.FeatureRecord(path) as rec:
+        st = {}
+        a = rec.upload_pixel_major(names, 'cuda:0', stats=st)
+        b = rec.upload_pixel_major(names, 'cuda:0', chunk=4, workers=3)
+        c = rec.upload_pixel_major(names[:1], 'cuda:0')
+        d = rec.upload_pixel_major(names, 'cpu', chunk=5)
+    ref = torch.from_numpy(np.stack([maps[k] for k in names])).permute(0, 2, 3, 1).contiguous()
+    assert a.shape == (n, h, w, D) and a.is_contiguous()
+    assert torch.equal(a.cpu(), ref) and torch.equal(b.cpu(), ref) and torch.equal(c.cpu(), ref[:1]) and torch.equal(d, ref)
+    assert st['bytes'] == n * D * h * w * 4

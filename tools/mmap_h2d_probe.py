@@ -75,6 +75,20 @@ for access, aname in ((mmap.ACCESS_COPY, 'private'), (mmap.ACCESS_WRITE, 'shared
 
     if access == mmap.ACCESS_COPY:
         rate(via_map, f'{aname} mapping, not registered -> device')
+        for T in (1, 2, 4, 8):
+            streams = [torch.cuda.Stream() for _ in range(T)]
+
+            def worker(t):
+                with torch.cuda.stream(streams[t]):
+                    for k in range(t, n, T):
+                        dst[k * piece:(k + 1) * piece].copy_(src[k * piece:(k + 1) * piece], non_blocking=True)
+                    streams[t].synchronize()
+
+            def via_map_threads():
+                with ThreadPoolExecutor(T) as ex:
+                    list(ex.map(worker, range(T)))
+
+            rate(via_map_threads, f'{aname} mapping, one 4 MB map per copy, {T} thread(s) / stream(s)')
     ptr = ctypes.addressof(ctypes.c_char.from_buffer(mm)) if access != mmap.ACCESS_READ else src.data_ptr()
     for flags, name in ((0, 'default'), (8, 'read-only flag')):
         rc = hip.hipHostRegister(ptr, arr.nbytes, flags)
