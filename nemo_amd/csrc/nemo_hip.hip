@@ -1568,11 +1568,12 @@ __global__ __launch_bounds__(FH_NT) void feature_head_kernel(const float *__rest
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, half = lane >> 5;
   const int nch = (C / 2 + FH_KS - 1) / FH_KS;     // chunks per tile
-  for (int k = tid; k < nch * FH_KS * 2 * D; k += FH_NT) {
-    // k = ((s * 2 + h) * 32 + r) * T + t  ->  weight[d = 32 t + r][c = 2 s + h]
-    const int t = k % T, r = (k / T) & 31, h = (k / (32 * T)) & 1, s2 = k / (64 * T);
-    const int c = 2 * s2 + h;
-    wl[k] = c < C ? weight[(size_t)(32 * t + r) * C + c] : 0.0f;
+  {
+    const int cpad = nch * FH_KS * 2;  // channels rounded up to whole chunks (zero weights past C)
+    for (int k = tid; k < D * cpad; k += FH_NT) {  // coalesced along the channels of one output row
+      const int d = k / cpad, c = k - d * cpad;
+      wl[(((c >> 1) * 2 + (c & 1)) * 32 + (d & 31)) * T + (d >> 5)] = c < C ? weight[(size_t)d * C + c] : 0.0f;
+    }
   }
   __syncthreads();
   const int tiles_per_img = (hw + 31) / 32;
