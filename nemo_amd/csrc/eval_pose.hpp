@@ -1,0 +1,702 @@
+// eval_pose.hpp -- the per-job evaluation (project -> rasterise -> face-major list -> fused interpolate + score -> backward) and its set-up helpers
+// Part of the single translation unit nemo_hip.hip (included from there, in order; not a stand-alone header).
+#ifndef EVAL_POSE_HPP
+#define EVAL_POSE_HPP
+
+namespace {
+
+// ---------------------------------------------------------------- the evaluation
+// Whole-workgroup routine.  Camera R (row-major) and T are read from L.ust; the
+// per-wave partial totals are left in L.red (see block_total) behind a barrier.
+// RAW = true: `feat` holds an upstream gradient dL/d(out) [h][w][D] of the
+// interpolated map and the routine back-propagates it (module path); otherwise
+// `feat` is the image feature map and the loss of MeshPoseSolveAll.py:58-59 is used.
+template <int D, bool PERSP, bool GRAD, bool SCORE, bool RAW = false, bool PRE = false, bool BIG = false, bool TAIL_SYNC = true>
+__device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, const float *__restrict__ feat,
+                          const float *__restrict__ clu, EmitOut emit, bool zb_clean = false,
+                          const float *__restrict__ vpre = nullptr) {
+#ifndef NEMO_KIT
+#define NEMO_KIT 2
+#endif
+  constexpr int KIT = NEMO_KIT;             // 16-byte loads per row per lane
+  constexpr int LPP = D / (4 * KIT);        // lanes per pixel: 16 (D=128) or 32 (D=256)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: everything derived from it lives in SGPRs
+  const int S = P.S;
+  const float Sf = (float)S;
+  const int V = M.V, F = M.F;
+  const float s = P.s;
+  const gf32p bank = as_global(M.bank);
+  const gf32p gverts = as_global(M.verts);
+  const gf32p gfeat = as_global(feat);
+  const gf32p gclu = as_global(clu);
+
+  STAMP_DECL;
+  if (!SCORE && tid < 16) L.ust[U_TOT + tid] = 0.0f;  // ordered before any use by the bounding-box barrier
+  // ---- 1. project vertices (MeshRasterizer.transform; order fixed in DESIGN.md)
+  float umin = 3.0e38f, umax = -3.0e38f, tmin = 3.0e38f, tmax = -3.0e38f;
+  {
+    const float *R = L.ust + U_R, *T = L.ust + U_T;
+    const float m00 = R[0] * s, m10 = R[3] * s, m20 = R[6] * s, m30 = T[0] * s;
+    const float m01 = R[1] * s, m11 = R[4] * s, m21 = R[7] * s, m31 = T[1] * s;
+    const float r02 = R[2], r12 = R[5], r22 = R[8], t2 = T[2];
+    int slot = 0;
+    for (int v = tid; v < V; v += NT, ++slot) {
+      // vpre: the caller loaded this thread's first two vertices ahead of time (solve kernel: under the Adam section)
+      const bool pre = vpre != nullptr && slot < 2;
+      const float x = pre ? vpre[3 * slot] : gverts[3 * v], y = pre ? vpre[3 * slot + 1] : gverts[3 * v + 1],
+                  z = pre ? vpre[3 * slot + 2] : gverts[3 * v + 2];
+      const float xc = ((x * m00 + y * m10) + z * m20) + m30;
+      const float yc = ((x * m01 + y * m11) + z * m21) + m31;
+      const float zv = ((x * r02 + y * r12) + z * r22) + t2;
+      const float u = xc / zv, t = yc / zv;
+      sv_put<BIG>(L, v, f4{u, t, zv, 0.0f});
+      umin = fminf(umin, u); umax = fmaxf(umax, u);
+      tmin = fminf(tmin, t); tmax = fmaxf(tmax, t);
+    }
+  }
+  umin = wave_min(umin); umax = wave_max(umax); tmin = wave_min(tmin); tmax = wave_max(tmax);
+  if (lane == 0) {
+    L.red[wave * RED_N + 0] = umin; L.red[wave * RED_N + 1] = umax;
+    L.red[wave * RED_N + 2] = tmin; L.red[wave * RED_N + 3] = tmax;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NW; ++k) {
+    umin = fminf(umin, L.red[k * RED_N + 0]); umax = fmaxf(umax, L.red[k * RED_N + 1]);
+    tmin = fminf(tmin, L.red[k * RED_N + 2]); tmax = fmaxf(tmax, L.red[k * RED_N + 3]);
+  }
+  // Flipped pixel indices a = S-1-col, b = S-1-row: pixel centre = ndc_of(a), ndc_of(b).
+  // Conservative index range of the object's bounding box, clipped to the window.
+  const int a_w0 = S - P.c0 - P.w, a_w1 = S - 1 - P.c0;  // window in flipped cols
+  const int b_w0 = S - P.r0 - P.h, b_w1 = S - 1 - P.r0;  // window in flipped rows
+  auto lo_idx = [&](float vmin) {
+    float f = ((fmaxf(fminf(vmin, 4.0f), -4.0f) + 1.0f) * Sf - 1.0f) * 0.5f;
+    return (int)floorf(f) - 1;
+  };
+  auto hi_idx = [&](float vmax_) {
+    float f = ((fmaxf(fminf(vmax_, 4.0f), -4.0f) + 1.0f) * Sf - 1.0f) * 0.5f;
+    return (int)ceilf(f) + 1;
+  };
+  // [lo, hi] = indices i in [clip_lo, clip_hi] with vmin <= ndc[i] <= vmax, exactly: ndc[] is monotone
+  // and the closed-form estimates floor(f) / ceil(f) are within [0, +2] / [-2, 0] of the answer
+  // (checked exhaustively in tests/test_host_cpu.py), so three table probes each settle it without a
+  // loop.  The table carries two extra entries on either side (indices -2 .. S+1).
+  auto exact_range = [&](float vmin, float vmax_, int clip_lo, int clip_hi, int &lo, int &hi) {
+    const int e = lo_idx(vmin) + 1, ec = hi_idx(vmax_) - 1;  // floor(f(vmin)), ceil(f(vmax))
+    auto at = [&](int i) { return L.ndc[min(max(i, -2), S + 1)]; };
+    const float l0 = at(e - 1), l1 = at(e), l2 = at(e + 1), h0 = at(ec + 1), h1 = at(ec), h2 = at(ec - 1);
+    lo = (e - 1) + (int)(l0 < vmin) + (int)(l1 < vmin) + (int)(l2 < vmin);
+    hi = (ec + 1) - (int)(h0 > vmax_) - (int)(h1 > vmax_) - (int)(h2 > vmax_);
+    lo = min(max(lo, clip_lo), clip_hi + 1);
+    hi = max(min(hi, clip_hi), clip_lo - 1);
+  };
+  // workgroup-uniform values read back from LDS live in VGPRs unless told otherwise
+  const int a_lo = __builtin_amdgcn_readfirstlane(max(lo_idx(umin), a_w0));
+  const int a_hi = __builtin_amdgcn_readfirstlane(min(hi_idx(umax), a_w1));
+  const int b_lo = __builtin_amdgcn_readfirstlane(max(lo_idx(tmin), b_w0));
+  const int b_hi = __builtin_amdgcn_readfirstlane(min(hi_idx(tmax), b_w1));
+  const int bw = a_hi - a_lo + 1;
+  const bool empty_box = (bw <= 0) || (b_hi < b_lo);
+  STAMP(0);
+
+  int ncov = 0, ebase = 0;
+
+  // ---- consumer of one band's face-major list (L.list[0..ntot)): emit or score; ends behind a barrier
+#ifdef NEMO_STAMPS
+  unsigned long long st_score0 = 0;
+#endif
+  float tot = 0.0f;  // wave 0, lane i < 13: running total i of the evaluation (T_LOSS, T_GR.., T_GT..)
+  auto consume = [&](const int ntot, const int ebase, const bool last) {
+    if (!SCORE) {
+      // pre-render: keep the list itself; standalone rasterizer: emit pix_to_face / bary / zbuf
+      if (emit.list_out)
+        for (int e = tid; e < ntot; e += NT) emit.list_out[ebase + e] = L.list[e];
+      for (int e = tid; emit.p2f && e < ntot; e += NT) {
+        const uint32_t ent = L.list[e];
+        const int p = (int)(ent & 0xffffu), f = (int)(ent >> 16);
+        const int i = (int)__umulhi((unsigned)p, P.w_magic), j = p - i * P.w;
+        const int a = S - 1 - (j + P.c0), b = S - 1 - (i + P.r0);
+        const us4 fv_ = fc_at<BIG>(L, f);
+        float v[9];
+        load_face_verts<BIG>(L, fv_.x, fv_.y, fv_.z, v);
+        Frag fr;
+        fr.b0 = fr.b1 = fr.b2 = fr.pz = -1.0f;
+        frag_eval<PERSP>(L.ndc[a], L.ndc[b], v, face_area_eps(v, P.keps), fr);
+        emit.p2f[p] = f;
+        emit.bary[3 * p] = fr.b0; emit.bary[3 * p + 1] = fr.b1; emit.bary[3 * p + 2] = fr.b2;
+        if (emit.zbuf) emit.zbuf[p] = fr.pz;
+      }
+    } else {
+      // ---- 3. fused interpolate + score (+ backward).  Each wave owns a contiguous
+      // segment of the face-major list and works through it in chunks of 64 pixels:
+      //  phase A (LPP lanes per pixel): 16-byte loads of the pixel's feature row and of
+      //    the face's three vertex-bank rows, three D-long dot products reduced with
+      //    DPP, results parked in a wave-private LDS buffer.  A lane group walks
+      //    consecutive list entries and re-reads a bank row only when that vertex slot
+      //    changes (the two triangles of a cuboid cell share two of their three slots).
+      //    The next entry's feature row is always in flight (ping-pong registers); the
+      //    prefetch is unconditional because a conditional load would make the compiler
+      //    drain vmcnt to zero every iteration.
+      //  phase B (one lane per pixel): barycentrics, object score, loss term and the
+      //    hand-derived backward to dL/dR, dL/dT accumulators.
+      // Both phases are wave-local (LDS operations of one wave complete in order), so
+      // there is no workgroup barrier inside this loop.  A wave keeps its 13 sums in registers over
+      // all its chunks, reduces them across lanes once (fixed DPP tree) and leaves them in L.red; the
+      // split of the list over the waves is a function of its length only, so the totals are
+      // reproducible bit for bit.
+      constexpr int GPW = 64 / LPP;
+      constexpr int NP = GRAD ? 13 : 1;  // partials per chunk: loss term, dL/dR (9), dL/dT (3)
+      const int gl = lane & (LPP - 1), grp = lane / LPP;
+#ifdef NEMO_STAMPS
+      st_score0 = __builtin_amdgcn_s_memrealtime();
+#endif
+      uint4 *rec = (uint4 *)L.zb + wave * CH;                               // [NW][CH]   (the z-buffer is dead by now
+      float *gbuf = (float *)((uint4 *)L.zb + NW * CH) + wave * (CH * 3);   // [NW][CH*3]  and hosts the wave-private scratch)
+      // rows are addressed as uniform base + 32-bit byte offset (feature window and bank are < 4 GiB)
+      typedef const __attribute__((address_space(1))) char *gbytep;
+      const gbytep fbytes = (gbytep)gfeat, bbytes = (gbytep)bank;
+      const uint32_t gl16 = (uint32_t)gl * 16u;
+      // byte offset of the feature row of this lane group's first entry in the chunk [cb_, cb_ + cn_)
+      auto first_off_at = [&](int cb_, int cn_) {
+        const int per_ = (cn_ + GPW - 1) / GPW;
+        return (L.list[cb_ + min(grp * per_, cn_ - 1)] & 0xffffu) * (uint32_t)(D * 4) + gl16;
+      };
+      f4 xa[KIT], xb[KIT];  // ping-pong: current / next feature-row fragments
+      // Static split: wave w owns the contiguous entries [ntot w / NW, ntot (w + 1) / NW) and walks them in
+      // chunks of CH; its 13 sums stay in registers across chunks and are reduced across lanes once.
+      const int seg_b = (ntot * wave) / NW, seg_e = (ntot * (wave + 1)) / NW;
+      float pl = 0.f;
+      float GR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      float GT[3] = {0.f, 0.f, 0.f};
+      int cb = seg_b;
+      if (cb < seg_e) {
+        const gf4p Fp = (gf4p)(fbytes + first_off_at(cb, min(CH, seg_e - cb)));
+#pragma unroll
+        for (int k = 0; k < KIT; ++k) xa[k] = __builtin_nontemporal_load(Fp + LPP * k);
+      }
+      while (cb < seg_e) {
+        const int cn = min(CH, seg_e - cb);
+        const int cb_next = cb + CH;
+        const int per = (cn + GPW - 1) / GPW;  // entries per lane group in this chunk
+        // ---------------- records (one lane per entry): everything phase A needs to know about an entry
+        // -- feature-row byte offset and the three bank rows -- is worked out once here, 64 entries per
+        // instruction, instead of by every lane of a group inside the loop.  The same pass fetches this
+        // lane's phase-B list entries and clutter scores (they land during phase A).
+        uint32_t ent_bs[CH / 64];
+        float cls[CH / 64];
+#pragma unroll
+        for (int u = 0; u < CH / 64; ++u) {
+          const uint32_t ent = L.list[cb + min(u * 64 + lane, cn - 1)];
+          ent_bs[u] = ent;
+          cls[u] = (P.clutter && clu) ? gclu[ent & 0xffffu] : 0.0f;
+          if (u * 64 < cn) {
+            const us4 fv_ = fc_at<BIG>(L, ent >> 16);
+            // register set k of phase A holds the bank row of vertex slot (code >> 2k) & 3 (MeshDesc::slot_order)
+            const uint32_t code = fv_.w;
+            auto slot_id = [&](uint32_t c) { return (uint32_t)(c == 0 ? fv_.x : (c == 1 ? fv_.y : fv_.z)); };
+            rec[u * 64 + lane] = uint4{(ent & 0xffffu) * (uint32_t)(D * 4),
+                                       slot_id(code & 3u) | (slot_id((code >> 2) & 3u) << 16), slot_id((code >> 4) & 3u), code};
+          }
+        }
+        // ---------------- phase A
+        {
+          // first feature row of this group in the wave's next chunk (or a harmless reload at the very end)
+          const int e0 = grp * per;
+          uint4 R0 = rec[min(e0, cn - 1)], R1 = rec[min(e0 + 1, cn - 1)];  // records run two entries ahead
+          const uint32_t off_next_chunk = cb_next < seg_e ? first_off_at(cb_next, min(CH, seg_e - cb_next)) : R0.x + gl16;
+          int i0 = -1, i1 = -1, i2 = -1;
+          f4 y0[KIT], y1[KIT], y2[KIT];
+#pragma unroll
+          for (int k = 0; k < KIT; ++k) y0[k] = y1[k] = y2[k] = f4{0.f, 0.f, 0.f, 0.f};
+          auto body = [&](int j, f4(&xc)[KIT], f4(&xnext)[KIT]) {
+            const int el = e0 + j;
+            const uint4 R2 = rec[min(el + 2, cn - 1)];
+            // 1st: the loads this entry depends on (bank rows of a changed vertex slot) ...
+            const int n0 = (int)(R0.y & 0xffffu), n1 = (int)(R0.y >> 16), n2 = (int)R0.z;
+            if (n0 != i0) {
+              i0 = n0;
+              const gf4p B = (gf4p)(bbytes + ((uint32_t)n0 * (uint32_t)(D * 4) + gl16));
+#pragma unroll
+              for (int k = 0; k < KIT; ++k) y0[k] = B[LPP * k];
+            }
+            if (n1 != i1) {
+              i1 = n1;
+              const gf4p B = (gf4p)(bbytes + ((uint32_t)n1 * (uint32_t)(D * 4) + gl16));
+#pragma unroll
+              for (int k = 0; k < KIT; ++k) y1[k] = B[LPP * k];
+            }
+            if (n2 != i2) {
+              i2 = n2;
+              const gf4p B = (gf4p)(bbytes + ((uint32_t)n2 * (uint32_t)(D * 4) + gl16));
+#pragma unroll
+              for (int k = 0; k < KIT; ++k) y2[k] = B[LPP * k];
+            }
+            // ... 2nd: the next entry's feature row, which stays in flight (vmcnt is in order)
+            {
+              const uint32_t offn = (j + 1 < per) ? R1.x + gl16 : off_next_chunk;
+              const gf4p Fp = (gf4p)(fbytes + offn);
+#pragma unroll
+              for (int k = 0; k < KIT; ++k)
+                xnext[k] = __builtin_nontemporal_load(Fp + LPP * k);
+            }
+            f4 A0 = xc[0] * y0[0], A1 = xc[0] * y1[0], A2 = xc[0] * y2[0];
+#pragma unroll
+            for (int k = 1; k < KIT; ++k) {
+              A0 = __builtin_elementwise_fma(xc[k], y0[k], A0);
+              A1 = __builtin_elementwise_fma(xc[k], y1[k], A1);
+              A2 = __builtin_elementwise_fma(xc[k], y2[k], A2);
+            }
+            float s0 = (A0.x + A0.y) + (A0.z + A0.w), s1 = (A1.x + A1.y) + (A1.z + A1.w),
+                  s2 = (A2.x + A2.y) + (A2.z + A2.w);
+            if (LPP >= 16) {
+              if (LPP >= 32) {
+                s0 += __shfl_xor(s0, 16); s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+              }
+              const float w = sum3_row16(s0, s1, s2);  // quad q of the row holds the total of value q (q < 3)
+              // value q belongs to vertex slot (code >> 2q) & 3: phase B reads the hand-off buffer in slot order
+              if (el < cn && (gl & 3) == 0 && gl < 12) gbuf[3 * el + ((R0.w >> ((gl >> 2) * 2)) & 3u)] = w;
+            } else {
+              const float g0 = sum8(s0), g1 = sum8(s1), g2 = sum8(s2);
+              if (gl == 0 && el < cn) {
+                gbuf[3 * el + (R0.w & 3u)] = g0; gbuf[3 * el + ((R0.w >> 2) & 3u)] = g1; gbuf[3 * el + ((R0.w >> 4) & 3u)] = g2;
+              }
+            }
+            R0 = R1; R1 = R2;
+          };
+          int j = 0;
+          for (; j + 1 < per; j += 2) {
+            body(j, xa, xb);
+            body(j + 1, xb, xa);
+          }
+          if (j < per) {  // odd tail: one more entry, then put the prefetched row back in xa
+            body(j, xa, xb);
+#pragma unroll
+            for (int k = 0; k < KIT; ++k) xa[k] = xb[k];
+          }
+        }
+        STAMP(8);
+        // ---------------- phase B: this lane's pixels -> its 13 contributions
+#pragma unroll
+        for (int u = 0; u < CH / 64; ++u)
+        if (u * 64 + lane < cn) {
+          const uint32_t ent_b = ent_bs[u];
+          const float cl = cls[u];
+          const int lb = u * 64 + lane;
+          const int p = (int)(ent_b & 0xffffu), f = (int)(ent_b >> 16);
+          const int pi = (int)__umulhi((unsigned)p, P.w_magic), pj = p - pi * P.w;
+          const int a = S - 1 - (pj + P.c0), b = S - 1 - (pi + P.r0);
+          const us4 fv_ = fc_at<BIG>(L, f);
+          const int i0 = fv_.x, i1 = fv_.y, i2 = fv_.z;
+          const float g0 = gbuf[3 * lb], g1 = gbuf[3 * lb + 1], g2 = gbuf[3 * lb + 2];
+          float v[9];
+          load_face_verts<BIG>(L, i0, i1, i2, v);
+          const float px = L.ndc[a], py = L.ndc[b];
+          // coverage was decided (exactly) by the rasterizer; the quantities below only feed the
+          // 1e-4-tolerance loss and gradient, so reciprocals replace IEEE divisions here
+          const float ia = __builtin_amdgcn_rcpf(face_area_eps(v, P.keps));
+          const float w0 = edge_fn(px, py, v[3], v[4], v[6], v[7]) * ia;
+          const float w1 = edge_fn(px, py, v[6], v[7], v[0], v[1]) * ia;
+          const float w2 = edge_fn(px, py, v[0], v[1], v[3], v[4]) * ia;
+          float b0 = w0, b1 = w1, b2 = w2, iden = 1.0f;
+          if (PERSP) {
+            const float t0 = (w0 * v[5]) * v[8], t1 = (v[2] * w1) * v[8], t2 = (v[2] * v[5]) * w2;
+            iden = __builtin_amdgcn_rcpf((t0 + t1) + t2);
+            b0 = t0 * iden; b1 = t1 * iden; b2 = t2 * iden;
+          }
+          const float obj = (b0 * g0 + b1 * g1) + b2 * g2;
+          float ind;
+          if (RAW) {
+            ind = 1.0f;
+          } else if (P.clutter) {
+            pl += fmaxf(obj, cl) - fmaxf(0.0f, cl);
+            ind = obj > cl ? 1.0f : (obj == cl ? 0.5f : 0.0f);
+          } else {
+            pl += obj;
+            ind = 1.0f;
+          }
+          if (GRAD && ind != 0.0f) {
+            const float up = RAW ? 1.0f : -P.inv_hw * ind;
+            const float gb0 = up * g0, gb1 = up * g1, gb2 = up * g2;
+            float gw0 = gb0, gw1 = gb1, gw2 = gb2, gz0 = 0.f, gz1 = 0.f, gz2 = 0.f;
+            if (PERSP) {
+              const float z0 = v[2], z1 = v[5], z2 = v[8];
+              const float dot = (gb0 * b0 + gb1 * b1) + gb2 * b2;
+              const float gt0 = (gb0 - dot) * iden, gt1 = (gb1 - dot) * iden, gt2 = (gb2 - dot) * iden;
+              gw0 = gt0 * z1 * z2; gw1 = gt1 * z0 * z2; gw2 = gt2 * z0 * z1;
+              gz0 = gt1 * w1 * z2 + gt2 * z1 * w2;
+              gz1 = gt0 * w0 * z2 + gt2 * z0 * w2;
+              gz2 = gt0 * w0 * z1 + gt1 * z0 * w1;
+            }
+            const float gE0 = gw0 * ia, gE1 = gw1 * ia, gE2 = gw2 * ia;
+            const float gA = -((gw0 * w0 + gw1 * w1) + gw2 * w2) * ia;
+            float gv[9];
+            gv[0] = gE1 * (v[7] - py) + gE2 * (py - v[4]) + gA * (v[7] - v[4]);
+            gv[1] = gE1 * (px - v[6]) + gE2 * (v[3] - px) + gA * (v[3] - v[6]);
+            gv[2] = gz0;
+            gv[3] = gE0 * (py - v[7]) + gE2 * (v[1] - py) + gA * (v[1] - v[7]);
+            gv[4] = gE0 * (v[6] - px) + gE2 * (px - v[0]) + gA * (v[6] - v[0]);
+            gv[5] = gz1;
+            gv[6] = gE0 * (v[4] - py) + gE1 * (py - v[1]) + gA * (v[4] - v[1]);
+            gv[7] = gE0 * (px - v[3]) + gE1 * (v[0] - px) + gA * (v[0] - v[3]);
+            gv[8] = gz2;
+            const int vi[3] = {i0, i1, i2};
+            const float inv_s = 1.0f / s, T0 = L.ust[U_T], T1 = L.ust[U_T + 1], T2 = L.ust[U_T + 2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const float iz = __builtin_amdgcn_rcpf(v[3 * c + 2]);
+              const float gxc = gv[3 * c] * iz, gyc = gv[3 * c + 1] * iz;
+              const float gzv = gv[3 * c + 2] - (gv[3 * c] * v[3 * c] + gv[3 * c + 1] * v[3 * c + 1]) * iz;
+              const float q0 = s * gxc, q1 = s * gyc, q2 = gzv;
+              // world vertex = (view - T) R^T: accumulate against (view - T) and rotate the 3x3 total once
+              // at the end (no world-space vertex table in LDS)
+              const float zs = v[3 * c + 2] * inv_s;
+              const float X0 = v[3 * c] * zs - T0, X1 = v[3 * c + 1] * zs - T1, X2 = v[3 * c + 2] - T2;
+              (void)vi;
+              GR[0] = fmaf(X0, q0, GR[0]); GR[1] = fmaf(X0, q1, GR[1]); GR[2] = fmaf(X0, q2, GR[2]);
+              GR[3] = fmaf(X1, q0, GR[3]); GR[4] = fmaf(X1, q1, GR[4]); GR[5] = fmaf(X1, q2, GR[5]);
+              GR[6] = fmaf(X2, q0, GR[6]); GR[7] = fmaf(X2, q1, GR[7]); GR[8] = fmaf(X2, q2, GR[8]);
+              GT[0] += q0; GT[1] += q1; GT[2] += q2;
+            }
+          }
+        }
+        STAMP(9);
+        cb = cb_next;
+      }
+      {  // the wave's partials (fixed DPP tree), left in L.red by one lane
+        float pv[13];
+        pv[0] = wave_sum_dpp(pl);
+        if (GRAD) {
+#pragma unroll
+          for (int i = 0; i < 9; ++i) pv[1 + i] = wave_sum_dpp(GR[i]);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) pv[10 + i] = wave_sum_dpp(GT[i]);
+        }
+        if (lane == 0) {
+#pragma unroll
+          for (int i = 0; i < NP; ++i) L.red[wave * RED_N + i] = pv[i];
+        }
+      }
+    }
+    STAMP(4);
+#ifdef NEMO_STAMPS
+    const unsigned long long st_arrive = __builtin_amdgcn_s_memrealtime();
+#endif
+    __syncthreads();  // all chunks of the band are done
+#ifdef NEMO_STAMPS
+    if (SCORE && (threadIdx.x & 63) == 0) {  // every wave: its wait at the band barrier, and its busy time in the score loop
+      atomicAdd(&g_stamps[10], __builtin_amdgcn_s_memrealtime() - st_arrive);
+      atomicAdd(&g_stamps[11], st_arrive - st_score0);
+      atomicAdd(&g_wave_busy[(threadIdx.x >> 6) & 15], st_arrive - st_score0);
+    }
+#endif
+    if (SCORE) {
+      // the waves' partials -> running totals, in wave order: lane i of wave 0 keeps total i in a register
+      constexpr int NPB = GRAD ? 13 : 1;
+      if (wave == 0 && lane < NPB) {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) tot += L.red[k * RED_N + lane];
+      }
+      // After the LAST band nothing of the band's LDS is reused before the caller's next barrier, and the totals
+      // live in wave 0's registers: no second barrier.
+      if (last) return;
+    }
+    __syncthreads();  // band's z-buffer / lists / L.red are reused by the next band
+    STAMP(5);
+  };
+
+
+  if (PRE) {
+    // pre-rendered pose (grid search): the face-major list was built once per (mesh, pose) by
+    // prerender_kernel; it is consumed in pieces of at most `cap` entries
+    for (int pb = 0; pb < emit.pre_cnt; pb += P.cap) {
+      const int ntot = min(P.cap, emit.pre_cnt - pb);
+      for (int i = tid; i < ntot; i += NT) L.list[i] = emit.pre_list[pb + i];
+      ncov += (tid == 0) ? ntot : 0;
+      __syncthreads();
+      consume(ntot, ebase, pb + P.cap >= emit.pre_cnt);
+      ebase += ntot;
+    }
+  } else if (!empty_box) {
+    const int rows_per_band = P.cap / bw;  // >= 1 because cap >= w >= bw
+    for (int bb = b_lo; bb <= b_hi; bb += rows_per_band) {
+      const int nr = min(rows_per_band, b_hi - bb + 1);
+      const int npx = nr * bw;
+      // ---- 2a. clear the band's z-buffer (zb_clean: the caller left all `cap` keys cleared behind a barrier)
+      if (!(zb_clean && bb == b_lo)) {
+        for (int i = tid; i < npx; i += NT) L.zb[i] = ~0ull;
+        __syncthreads();
+      }
+      STAMP(1);
+      // ---- 2b. face-parallel rasterisation (one thread per face).  The candidate pixel centres of a face
+      // (its exact bounding-box ranges) are walked as ONE flat loop, so a wave runs max-over-lanes of the
+      // candidate COUNT, not of rows x columns; the sign pre-test is branch-free; the three quotients
+      // e_k / area use the hoisted exact division (fastdiv.h), the IEEE expansion only for operands outside
+      // its safe range.  Every accepted fragment sees the same operations, in the same order, as the oracle.
+      for (int f = tid; f < F; f += NT) {
+        const us4 fv_ = fc_at<BIG>(L, f);
+        const int i0 = fv_.x, i1 = fv_.y, i2 = fv_.z;
+        float v[9];
+        load_face_verts<BIG>(L, i0, i1, i2, v);
+        u4v rec = u4v{1u, 1u | (1u << 31), 0u, 0u};  // empty box, empty mask
+        if (!face_degenerate(v, P.keps)) {
+          const float xmin = fminf(fminf(v[0], v[3]), v[6]), xmax = fmaxf(fmaxf(v[0], v[3]), v[6]);
+          const float ymin = fminf(fminf(v[1], v[4]), v[7]), ymax = fmaxf(fmaxf(v[1], v[4]), v[7]);
+          // exact index ranges of the pixel centres inside the face's bounding box (the test
+          // PyTorch3D applies per pixel), clipped to the object box / band
+          int fa_lo, fa_hi, fb_lo, fb_hi;
+          exact_range(xmin, xmax, a_lo, a_hi, fa_lo, fa_hi);
+          exact_range(ymin, ymax, bb, bb + nr - 1, fb_lo, fb_hi);
+          if (fa_lo <= fa_hi && fb_lo <= fb_hi) {
+            const float area0 = face_area_eps(v, P.keps);
+            const int na = fa_hi - fa_lo + 1, nb = fb_hi - fb_lo + 1, ncand = na * nb;
+            const bool use_mask = na <= 8 && nb <= 8;
+            // Orientation: with a negative area every edge value and the area are negated (exact, and
+            // e / area == (-e) / (-area) bit for bit), so the pre-test below is "all edge values > 0"
+            // for either winding.  odd: zero / NaN area, no pre-test possible.
+            const bool odd = !(area0 > 0.0f || area0 < 0.0f);
+            const float sg = area0 < 0.0f ? -1.0f : 1.0f;
+            const float area = area0 * sg;
+            // edge(p; a, b) = (p.x - a.x)(b.y - a.y) - (p.y - a.y)(b.x - a.x): the per-face and per-row factors
+            const float dy0 = (v[7] - v[4]) * sg, dx0 = (v[6] - v[3]) * sg;
+            const float dy1 = (v[1] - v[7]) * sg, dx1 = (v[0] - v[6]) * sg;
+            const float dy2 = (v[4] - v[1]) * sg, dx2 = (v[3] - v[0]) * sg;
+            const FastDiv fd(area);
+            // |edge value| <= 4 M (1 + M) for pixel centres in [-1, 1] and |vertex x, y| <= M: with M <= 2^18
+            // only the lower end of FastDiv's safe range is left to check per candidate.
+            const float mabs = fmaxf(fmaxf(fabsf(xmin), fabsf(xmax)), fmaxf(fabsf(ymin), fabsf(ymax)));
+            const float thr = (fd.d_safe && mabs <= 0x1p18f && !odd) ? 0x1p-40f : INFINITY;
+            int a = fa_lo, b = fb_lo, bit = 0;
+            float py = L.ndc[b];
+            float r0 = (py - v[4]) * dx0, r1 = (py - v[7]) * dx1, r2 = (py - v[1]) * dx2;
+            int ha_lo = 0x7fff, ha_hi = -1, hb_lo = 0x7fff, hb_hi = -1;
+            u64 fmask = 0;
+            u64 *zrow = L.zb + ((b - bb) * bw - a_lo);
+            for (int c = 0; c < ncand; ++c) {
+              const float px = L.ndc[a];
+              const float e0 = (px - v[3]) * dy0 - r0;
+              const float e1 = (px - v[6]) * dy1 - r1;
+              const float e2 = (px - v[0]) * dy2 - r2;
+              // the quotients can only all be > 0 if every (oriented) edge value is; min3 skips NaNs, which
+              // the explicit comparisons on the quotients below reject like the reference does
+              const float m = PERSP ? fminf(fminf(fabsf(e0), fabsf(e1)), fabsf(e2)) : fminf(fminf(e0, e1), e2);
+              if (PERSP || odd || m > 0.0f) {
+                float w0, w1, w2;
+                if (m >= thr) {
+                  w0 = fd.div(e0); w1 = fd.div(e1); w2 = fd.div(e2);
+                } else {
+                  w0 = e0 / area; w1 = e1 / area; w2 = e2 / area;
+                }
+                float b0 = w0, b1 = w1, b2 = w2;
+                if (PERSP) {
+                  const float t0 = (w0 * v[5]) * v[8];
+                  const float t1 = (v[2] * w1) * v[8];
+                  const float t2 = (v[2] * v[5]) * w2;
+                  const float den = (t0 + t1) + t2;
+                  b0 = t0 / den; b1 = t1 / den; b2 = t2 / den;
+                }
+                const float pz = (b0 * v[2] + b1 * v[5]) + b2 * v[8];
+                if (!(pz < 0.0f) && b0 > 0.0f && b1 > 0.0f && b2 > 0.0f) {
+                  const u64 key = ((u64)__float_as_uint(pz + 0.0f) << 32) | (u64)(uint32_t)f;  // -0 -> +0: key order = float order
+                  atomicMin(&zrow[a], key);
+                  fmask |= 1ull << (bit & 63);
+                  if (__builtin_expect(!use_mask, 0)) {
+                    ha_lo = min(ha_lo, a); ha_hi = max(ha_hi, a);
+                    hb_lo = min(hb_lo, b); hb_hi = max(hb_hi, b);
+                  }
+                }
+              }
+              ++a; ++bit;
+              if (a > fa_hi) {  // next row of the candidate box (the NDC table has two spare entries past S - 1)
+                a = fa_lo; ++b; bit += 8 - na;
+                zrow += bw;
+                py = L.ndc[b];
+                r0 = (py - v[4]) * dx0; r1 = (py - v[7]) * dx1; r2 = (py - v[1]) * dx2;
+              }
+            }
+            if (use_mask) {
+              rec = u4v{(uint32_t)fa_lo | ((uint32_t)fa_hi << 16), (uint32_t)fb_lo | ((uint32_t)fb_hi << 16) | (1u << 31),
+                          (uint32_t)fmask, (uint32_t)(fmask >> 32)};
+            } else {
+              if (ha_hi < 0) { ha_lo = hb_lo = 1; ha_hi = hb_hi = 0; }
+              rec = u4v{(uint32_t)ha_lo | ((uint32_t)ha_hi << 16), (uint32_t)hb_lo | ((uint32_t)hb_hi << 16), 0u, 0u};
+            }
+          }
+        }
+        finfo_put<BIG>(L, f, rec);
+      }
+      __syncthreads();
+      STAMP(2);
+      // ---- 2c. face-major list of the covered pixels: ordered by winning face, then
+      // row-major.  Thread t owns the contiguous face run [t*fpl, (t+1)*fpl), so a
+      // block-wide exclusive scan of the per-thread counts gives every thread its slot
+      // range; the order (hence every later float sum) is deterministic.  An entry
+      // packs (face id << 16) | window pixel index, all the score phases need.
+      // Masked faces: the count pass visits only the pixels where the face produced a fragment and
+      // leaves the mask of those it won in the record; the fill pass visits only the winners.
+      const uint32_t *zlo = (const uint32_t *)L.zb;  // low dword of a key = face id
+      const int fpl = (F + NT - 1) / NT;
+      const int fbeg = min(F, tid * fpl), fend = min(F, fbeg + fpl);
+      auto zface = [&](int a, int b) { return zlo[2 * ((b - bb) * bw + (a - a_lo))]; };
+      auto pack = [&](int f, int a, int b) {
+        return ((uint32_t)f << 16) | (uint32_t)((S - 1 - b - P.r0) * P.w + (S - 1 - a - P.c0));
+      };
+      int cnt = 0;
+      for (int f = fbeg; f < fend; ++f) {
+        const u4v fi = finfo_at<BIG>(L, f);
+        const int fa_lo = fi.x & 0xffffu, fa_hi = fi.x >> 16, fb_lo = fi.y & 0xffffu, fb_hi = (fi.y >> 16) & 0x7fffu;
+        if (fi.y >> 31) {
+          u64 m = (u64)fi.z | ((u64)fi.w << 32), won = 0;
+          if (m == 0) continue;
+          while (m) {
+            const int c = __builtin_ctzll(m);
+            m &= m - 1;
+            if (zface(fa_lo + (c & 7), fb_lo + (c >> 3)) == (uint32_t)f) won |= 1ull << c;
+          }
+          cnt += __builtin_popcountll(won);
+          finfo_put_mask<BIG>(L, f, won);
+        } else {
+          for (int b = fb_lo; b <= fb_hi; ++b)
+            for (int a = fa_lo; a <= fa_hi; ++a) cnt += (int)(zface(a, b) == (uint32_t)f);
+        }
+      }
+      int incl = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+      }
+      int *ired = (int *)L.red;
+      if (lane == 63) ired[wave * RED_N + 8] = incl;
+      __syncthreads();
+      int slot = incl - cnt, ntot = 0;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        const int t = ired[k * RED_N + 8];
+        slot += (k < wave) ? t : 0;
+        ntot += t;
+      }
+      ntot = __builtin_amdgcn_readfirstlane(ntot);
+      if (cnt > 0)
+        for (int f = fbeg; f < fend; ++f) {
+          const u4v fi = finfo_at<BIG>(L, f);
+          const int fa_lo = fi.x & 0xffffu, fa_hi = fi.x >> 16, fb_lo = fi.y & 0xffffu, fb_hi = (fi.y >> 16) & 0x7fffu;
+          if (fi.y >> 31) {
+            u64 m = (u64)fi.z | ((u64)fi.w << 32);  // winners, row-major (bit order = b, then a)
+            while (m) {
+              const int c = __builtin_ctzll(m);
+              m &= m - 1;
+              L.list[slot++] = pack(f, fa_lo + (c & 7), fb_lo + (c >> 3));
+            }
+          } else {
+            for (int b = fb_lo; b <= fb_hi; ++b)
+              for (int a = fa_lo; a <= fa_hi; ++a)
+                if (zface(a, b) == (uint32_t)f) L.list[slot++] = pack(f, a, b);
+          }
+        }
+      ncov += (tid == 0) ? ntot : 0;
+      __syncthreads();
+      STAMP(3);
+      consume(ntot, ebase, bb + rows_per_band > b_hi);
+      ebase += ntot;
+    }
+  }
+
+  // ---- 4. totals -> L.ust[U_TOT..]: lane i of wave 0 holds total i; thread 0 collects them (readlane), rotates the
+  // gradient (dL/dR = R * sum((view - T)^T q)) and publishes all 14.  TAIL_SYNC = false (solve kernel): no closing
+  // barrier -- thread 0 itself goes on to the camera backward and Adam, the caller's own barrier publishes.
+  if (SCORE) {
+    if (wave == 0) {
+      float tv[13];
+#pragma unroll
+      for (int i = 0; i < 13; ++i) tv[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), i));
+      if (tid == 0) {
+        L.ust[U_TOT + T_LOSS] = tv[0];
+        L.ust[U_TOT + T_NCOV] = (float)ncov;
+        if (GRAD) {
+          const float *R = L.ust + U_R;
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+              L.ust[U_TOT + T_GR + 3 * i + j] = (R[3 * i] * tv[1 + j] + R[3 * i + 1] * tv[4 + j]) + R[3 * i + 2] * tv[7 + j];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) L.ust[U_TOT + T_GT + i] = tv[10 + i];
+        }
+      }
+    }
+  } else if (tid == 0) {
+    L.ust[U_TOT + T_NCOV] = (float)ncov;
+  }
+  if (TAIL_SYNC) __syncthreads();
+  STAMP(6);
+}
+
+// Per-image loss constant: L = K - inv_hw * sum_cov(max(obj,clu) - max(0,clu)),
+// K = 1 + mean(clu) - mean(max(0,clu))   (loss_fun, code/MeshPoseSolveAll.py:58-59).
+// Thread 0 leaves it in L.ust[U_K].
+__device__ void loss_constant(const KParams &P, const Lds &L, const float *__restrict__ clu) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (!(P.clutter && clu)) {
+    if (tid == 0) L.ust[U_K] = 1.0f;
+    __syncthreads();
+    return;
+  }
+  double a = 0.0;
+  const gf32p gclu = as_global(clu);
+  for (int i = tid; i < P.h * P.w; i += NT) a += (double)fminf(gclu[i], 0.0f);  // clu - max(0,clu)
+  float d = wave_sum((float)a);
+  if (lane == 0) L.red[wave * RED_N] = d;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) t += L.red[k * RED_N];
+    L.ust[U_K] = 1.0f + t * P.inv_hw;
+  }
+  __syncthreads();
+}
+
+// Per-kernel LDS set-up: face vertex ids as 8-byte records and the table of pixel-centre
+// NDC coordinates (the exact PixToNdc values, computed once instead of per pixel test).
+template <bool BIG>
+__device__ __forceinline__ void load_world_verts(const KParams &P, const Lds &L, const MeshDesc &M) {
+  const gi32p gf = as_global(M.faces);
+  const gf32p gv = as_global(M.verts);
+  const uint8_t GAS *so = as_global(M.slot_order);
+  for (int i = threadIdx.x; i < M.F; i += NT)
+    fc_put<BIG>(L, i, us4{(unsigned short)gf[3 * i], (unsigned short)gf[3 * i + 1], (unsigned short)gf[3 * i + 2],
+                          (unsigned short)(M.slot_order ? so[i] : 0x24)});
+  for (int i = (int)threadIdx.x - 2; i < P.S + 2; i += NT) L.ndc[i] = ndc_of(i, (float)P.S);
+  __syncthreads();
+}
+
+// Thread-0 helpers working on the uniform state in LDS.
+static_assert(sizeof(Cam) == 35 * sizeof(float) && U_CAM + 35 <= UST_N, "camera slot");
+__device__ __forceinline__ void ust_set_camera(const Lds &L, const float *Cp, float theta, Cam &cam,
+                                               const float *extra = nullptr) {
+  dev_camera(Cp, theta, extra, cam);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) L.ust[U_R + i] = cam.R[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) L.ust[U_T + i] = cam.T[i];
+  const float *cf = (const float *)&cam;  // kept for the camera backward of this iterate
+#pragma unroll
+  for (int i = 0; i < 35; ++i) L.ust[U_CAM + i] = cf[i];
+}
+__device__ __forceinline__ void ust_get_camera(const Lds &L, Cam &cam) {
+  float *cf = (float *)&cam;
+#pragma unroll
+  for (int i = 0; i < 35; ++i) cf[i] = L.ust[U_CAM + i];
+}
+__device__ __forceinline__ void ust_totals_to_grad(const Lds &L, const Cam &cam, const float *Cp, float g[4]) {
+  float GR[9], GT[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) GR[i] = block_total(L, T_GR + i);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) GT[i] = block_total(L, T_GT + i);
+  dev_camera_bwd(cam, Cp, GR, GT, g, g[3]);
+}
+
+}  // namespace
+
+#endif  // EVAL_POSE_HPP

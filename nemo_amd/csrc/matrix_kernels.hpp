@@ -1,0 +1,560 @@
+// matrix_kernels.hpp -- kernels on the fp32 matrix cores (v_mfma_f32_32x32x2_f32): dense grid search, backbone tail, clutter contraction; the streaming clutter kernel
+// Part of the single translation unit nemo_hip.hip (included from there, in order; not a stand-alone header).
+#ifndef MATRIX_KERNELS_HPP
+#define MATRIX_KERNELS_HPP
+
+namespace {
+
+// ---------------------------------------------------------------- grid search on the matrix cores
+// get_init_pos_rendered (code/MeshPoseSolveAll.py:84-100) compares an image with the stored renders of all
+// grid poses: object_score[g, p] = sum_d render[g, p, d] * feature[p, d].  With the renders of a (mesh, grid)
+// pair kept as dense pixel-major maps (nemo_grid_prerender) that is, per pixel, a small GEMM
+//   [jobs of the pair] x D  times  D x [G poses]
+// whose operands are read once.  A workgroup owns (pair, chunk of GP_PIX pixels); wave w owns the 32 poses
+// 32w..32w+31 and walks the pair's jobs 32*GP_TILES at a time with v_mfma_f32_32x32x2_f32 (exact fp32 FMA
+// chains); the loss terms max(obj, clu) - max(0, clu) are summed over the chunk's pixels in registers and
+// left as per-chunk partials, which grid_finish_kernel adds in chunk order (deterministic).
+constexpr int GP_PIX = 64;
+#ifndef NEMO_GP_TILES
+#define NEMO_GP_TILES 2
+#endif
+constexpr int GP_TILES = NEMO_GP_TILES;
+constexpr int GP_MAX_PAIRS = 2048;
+
+__global__ void gather_pose_kernel(int n, const int32_t *gidx, const float *gridC, const float *gridTheta, float *C, float *theta) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int g = gidx[k];
+  C[3 * k] = gridC[3 * g]; C[3 * k + 1] = gridC[3 * g + 1]; C[3 * k + 2] = gridC[3 * g + 2];
+  theta[k] = gridTheta[g];
+}
+
+// Render jobs of one pose block: job (pair i, block pose b) -> its mesh and its index into the grid arrays.
+__global__ void block_jobs_kernel(int n_pairs, int G, int g0, int gb, const int32_t *pair_mesh, const int32_t *pair_grid,
+                                  int32_t *mesh_out, int32_t *gidx_out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_pairs * gb) return;
+  const int i = k / gb, b = k - i * gb;
+  mesh_out[k] = pair_mesh[i];
+  gidx_out[k] = pair_grid[i] * G + g0 + b;
+}
+
+// chunk_live[pair][chunk] = 1 if any pose of the block [g0, g0 + gb) covers a pixel of the chunk (from the stored lists).
+__global__ void chunk_live_kernel(int G, int g0, int gb, int n_chunks, size_t stride, const uint32_t *list,
+                                  const int32_t *cnt, uint8_t *live) {
+  const int sl = blockIdx.x / gb, g = g0 + blockIdx.x % gb;
+  const size_t pg = (size_t)sl * G + g;
+  const uint32_t *l = list + pg * stride;
+  for (int e = threadIdx.x; e < cnt[pg]; e += blockDim.x) live[sl * n_chunks + (int)((l[e] & 0xffffu) / GP_PIX)] = 1;
+}
+
+// Jobs grouped by pre-render slot: order[] lists the job ids slot by slot, slot_start[] the ranges,
+// job_slot[n] the slot of job n (-1: not pre-rendered, evaluated on the fly by grid_kernel).
+__global__ __launch_bounds__(1024) void grid_group_kernel(int N, const int32_t *mesh_idx, const int32_t *grid_idx,
+                                                          const int32_t *slot_tab, int n_pairs, int32_t *order,
+                                                          int32_t *slot_start, int32_t *job_slot, int32_t *work) {
+  __shared__ int cnt[GP_MAX_PAIRS + 1];
+  __shared__ int n_work;
+  for (int i = threadIdx.x; i <= n_pairs; i += blockDim.x) cnt[i] = 0;
+  if (threadIdx.x == 0) n_work = 0;
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    const int mi = mesh_idx ? mesh_idx[n] : 0, gi = grid_idx ? grid_idx[n] : 0;
+    const int sl = gi < MAX_GRIDS ? slot_tab[mi * MAX_GRIDS + gi] : -1;
+    job_slot[n] = sl;
+    if (sl >= 0) atomicAdd(&cnt[sl], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int i = 0; i < n_pairs; ++i) {
+      const int c = cnt[i];
+      slot_start[i] = run;
+      cnt[i] = run;  // becomes the placement cursor
+      run += c;
+    }
+    slot_start[n_pairs] = run;
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    const int sl = job_slot[n];
+    if (sl >= 0) order[atomicAdd(&cnt[sl], 1)] = n;  // order inside a slot is irrelevant: jobs are independent
+    else work[1 + atomicAdd(&n_work, 1)] = n;        // left to grid_kernel (rendered on the fly / list path)
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) work[0] = n_work;
+}
+
+// Both operands are staged through LDS.  Per pixel the workgroup needs the feature rows
+// of the pass's jobs (A, JTW tiles of 32 rows) and the rendered rows of its poses (B, PTW tiles of 32 rows): each
+// row is read from HBM once, coalesced, by the whole workgroup (one pixel ahead, through registers) instead of
+// once per wave with 16-byte gathers, and wave w multiplies tile (jt, pt) = (w / PTW, w % PTW) out of LDS.  Rows
+// are padded to 132 floats, which makes the 16-byte operand reads of a 16-lane group conflict-free.  For
+// D = 256 a pixel is staged in two halves of 128 features.
+// Pose blocks: `maps` holds the renders of Gb consecutive grid poses [g_off, g_off + Gb) of every pair (all G of them
+// when the store fits its budget, otherwise nemo_grid_search renders block after block into the same buffer);
+// `chunk_live` (optional) says per (pair, pixel chunk) whether ANY pose of the block covers a pixel of the chunk --
+// if none does, every object score is 0, every loss term max(0, clu) - max(0, clu) = 0, and the chunk is skipped.
+constexpr int GQ_ROW = 132;
+template <int D>
+__global__ __launch_bounds__(1024) void grid_mfma_lds_kernel(int hw, int N, int G, int Gb, int g_off, int n_chunks, int PTW,
+                                                             int JTW, const int32_t *img_idx, const int32_t *order,
+                                                             const int32_t *slot_start, const float *__restrict__ feat,
+                                                             const float *__restrict__ clu,
+                                                             const float *__restrict__ maps, float *__restrict__ partial,
+                                                             const uint8_t *__restrict__ chunk_live, int clutter_on) {
+  extern __shared__ __align__(16) float gq_sm[];
+  constexpr int KH = D / 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, half = lane >> 5;
+  const int sl = blockIdx.x / n_chunks, c = blockIdx.x % n_chunks;
+  const int js = slot_start[sl], ns = slot_start[sl + 1] - js;
+  if (ns == 0) return;
+  const int p0 = c * GP_PIX, np = min(GP_PIX, hw - p0);
+  const int g0 = (int)blockIdx.y * PTW * 32;      // first pose of this workgroup, relative to the block
+  if (chunk_live && !chunk_live[sl * n_chunks + c]) {
+    const int ng = min(PTW * 32, Gb - g0);
+    for (int k = tid; k < ns * ng; k += 1024)
+      partial[((size_t)c * N + order[js + k / ng]) * G + g_off + g0 + k % ng] = 0.0f;
+    return;
+  }
+  const int nrowsA = JTW * 32, NS = PTW + JTW;  // slab k of 32 rows: A for k < JTW, B after
+  float *As = gq_sm, *Bs = gq_sm + nrowsA * GQ_ROW, *cls = gq_sm + NS * 32 * GQ_ROW;
+  const int pt = wave % PTW, jt = wave / PTW;
+  const bool active = jt < JTW;
+  const int srow = tid >> 5, sc4 = tid & 31;  // staging: row within the slab, 16-byte column
+  for (int tg = 0; tg < ns; tg += nrowsA) {
+    const float *rp[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      rp[k] = nullptr;
+      if (k < JTW) {
+        const int job = order[js + min(tg + k * 32 + srow, ns - 1)];
+        const int img = img_idx ? img_idx[job] : job;
+        rp[k] = feat + ((size_t)img * hw + p0) * D + sc4 * 4;
+      } else if (k < NS) {
+        const int g = min(g0 + (k - JTW) * 32 + srow, Gb - 1);
+        rp[k] = maps + (((size_t)sl * Gb + g) * hw + p0) * D + sc4 * 4;
+      }
+    }
+    const float *clp = nullptr;
+    if (clutter_on && tid < nrowsA) {
+      const int job = order[js + min(tg + tid, ns - 1)];
+      clp = clu + (size_t)(img_idx ? img_idx[job] : job) * hw + p0;
+    }
+    f16v lsum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lsum[r] = 0.0f;
+    f4 st[8];
+    float clv = 0.0f;
+    auto fetch = [&](int p, int kh) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k < NS) st[k] = __builtin_nontemporal_load((const f4 *)(rp[k] + (size_t)p * D + kh * 128));
+      if (kh == 0 && clp) clv = clp[p];
+    };
+    fetch(0, 0);
+    for (int p = 0; p < np; ++p) {
+      f16v acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+      for (int kh = 0; kh < KH; ++kh) {
+        __syncthreads();  // the previous stage has been consumed
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k < NS) *(f4 *)&gq_sm[(k * 32 + srow) * GQ_ROW + sc4 * 4] = st[k];
+        if (kh == 0 && tid < nrowsA) cls[tid] = clv;
+        __syncthreads();
+        if (kh + 1 < KH) fetch(p, kh + 1);
+        else if (p + 1 < np) fetch(p + 1, 0);
+        if (active) {
+          const float *ap = As + (jt * 32 + i) * GQ_ROW + 4 * half, *bp = Bs + (pt * 32 + i) * GQ_ROW + 4 * half;
+#pragma unroll 4
+          for (int q = 0; q < 16; ++q) {
+            const f4 a = *(const f4 *)(ap + 8 * q), b = *(const f4 *)(bp + 8 * q);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+          }
+        }
+      }
+      // C/D layout: column = lane & 31 (pose), row = (r & 3) + 8 * (r >> 2) + 4 * half (job of the tile)
+      if (active) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const f4 cv = *(const f4 *)&cls[jt * 32 + 8 * k + 4 * half];
+          const float cc[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float o = acc[4 * k + r];
+            lsum[4 * k + r] += clutter_on ? (fmaxf(o, cc[r]) - fmaxf(0.0f, cc[r])) : o;
+          }
+        }
+      }
+    }
+    if (active) {
+      const int g = g0 + pt * 32 + i;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int jrow = tg + jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (jrow < ns && g < Gb) partial[((size_t)c * N + order[js + jrow]) * G + g_off + g] = lsum[r];
+      }
+    }
+    __syncthreads();  // the next pass restages the LDS
+  }
+}
+
+// loss[n][g] = K_n - (1/hw) * sum over chunks (chunk order), K_n = 1 + mean(min(clu, 0)) (loss_constant).
+__global__ __launch_bounds__(256) void grid_finish_kernel(int hw, float inv_hw, int N, int G, int n_chunks,
+                                                          const int32_t *img_idx, const int32_t *job_slot,
+                                                          const float *clu, const float *partial,
+                                                          const int32_t *pre_cnt, float *losses, u64 *counter,
+                                                          int clutter_on) {
+  __shared__ double red[256];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int sl = job_slot[n];
+  if (sl < 0) return;
+  double a = 0.0;
+  if (clutter_on) {
+    const float *c = clu + (size_t)(img_idx ? img_idx[n] : n) * hw;
+    for (int k = tid; k < hw; k += 256) a += (double)fminf(c[k], 0.0f);
+  }
+  red[tid] = a;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const float K = 1.0f + (float)red[0] * inv_hw;
+  u64 cov = 0;
+  for (int g = tid; g < G; g += 256) {
+    float s = 0.0f;
+    for (int c = 0; c < n_chunks; ++c) s += partial[((size_t)c * N + n) * G + g];
+    losses[(size_t)n * G + g] = K - inv_hw * s;
+    cov += (u64)pre_cnt[(size_t)sl * G + g];
+  }
+  if (counter && cov) atomicAdd(counter, cov);
+}
+
+// ---------------------------------------------------------------- backbone tail
+// NetE2E.forward_test after the backbone (code/models/KeypointRepresentationNet.py:217-223): the 1x1 convolution
+// with out_layer.weight [D][C] (no bias), F.normalize over the D channels (eps 1e-12), and -- fused -- the clutter
+// score of code/MeshPoseSolveAll.py:220.  Input x is the backbone's [N][C][h*w] map; the output is written
+// directly in the solver's pixel-major layout [N][h*w][D].
+// out[d, p] = sum_c W[d, c] x[c, p] runs on v_mfma_f32_32x32x2_f32: A = 32 output channels (D/32 tiles kept in
+// accumulators), B = 32 consecutive pixels of one image (coalesced dword loads per channel), the whole weight
+// matrix staged once per workgroup in LDS in the order the lanes consume it (one 16-byte read per k-step and four
+// output tiles).  Workgroups are persistent.  The LDS-resident weights leave room for one workgroup -- two waves
+// per SIMD -- per CU, so little but the wave's own instruction stream hides latency: the channels go through in
+// chunks of 2 * FH_KS, branch-free and fully unrolled; the B operands of the NEXT chunk (the next tile's first
+// chunk after a tile's last) are loaded into the other half of a register ping-pong one by one between the groups
+// of matrix instructions of this chunk (a whole chunk = FH_KS x 4 x 64 cycles ahead of their use), and the A
+// operands are read from LDS one k-step ahead.  Measured (tools/prof_head.py, 512 images, C = 256 -> D = 128):
+// 2.45 ms = 110 TFLOP/s, 0.70 of the fp32 matrix peak (the branchy per-k-step version it replaces: 66).
+constexpr int FH_KS = 32;  // k-steps (channel pairs) per chunk
+constexpr int FH_NT = 512, FH_NW = FH_NT / 64;  // two waves per SIMD, 256 registers each: accumulators 64 (D = 128), B ping-pong 64
+template <int D>
+__global__ __launch_bounds__(FH_NT) void feature_head_kernel(const float *__restrict__ x, int N, int C, int hw,
+                                                             const float *__restrict__ weight,
+                                                             const float *__restrict__ cbank, int K,
+                                                             float *__restrict__ feat, float *__restrict__ clu) {
+  constexpr int T = D / 32;                        // output-channel tiles
+  extern __shared__ __align__(16) float wl[];      // [ceil(C/2 / FH_KS) * FH_KS][2][32][T]: (k-step, half, row in tile, tile); zero past C
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, half = lane >> 5;
+  const int nch = (C / 2 + FH_KS - 1) / FH_KS;     // chunks per tile
+  {
+    const int cpad = nch * FH_KS * 2;  // channels rounded up to whole chunks (zero weights past C)
+    for (int k = tid; k < D * cpad; k += FH_NT) {  // coalesced along the channels of one output row
+      const int d = k / cpad, c = k - d * cpad;
+      wl[(((c >> 1) * 2 + (c & 1)) * 32 + (d & 31)) * T + (d >> 5)] = c < C ? weight[(size_t)d * C + c] : 0.0f;
+    }
+  }
+  __syncthreads();
+  const int tiles_per_img = (hw + 31) / 32;
+  const long long total = (long long)N * tiles_per_img;
+  const size_t hw2 = 2 * (size_t)hw;
+  // address of this lane's B value of k-step 0 of chunk `ch` of tile `tile`: channel 2 (ch FH_KS) + half of pixel p0 + i
+  auto b_ptr = [&](long long tile, int ch) {
+    const int n = (int)(tile / tiles_per_img), p0 = (int)(tile - (long long)n * tiles_per_img) * 32;
+    return x + ((size_t)n * C + half + 2 * ch * FH_KS) * hw + min(p0 + i, hw - 1);
+  };
+  const long long stride = (long long)gridDim.x * FH_NW;
+  long long tile = (long long)blockIdx.x * FH_NW + wave;
+  if (tile >= total) return;
+  int ch = 0;
+  f16v acc[T];
+  float b0[FH_KS], b1[FH_KS];
+  {
+    const float *xq = b_ptr(tile, 0);
+    const int nv = min(FH_KS, C / 2);
+#pragma unroll
+    for (int s2 = 0; s2 < FH_KS; ++s2) {
+      b0[s2] = __builtin_nontemporal_load(xq);
+      xq += s2 + 1 < nv ? hw2 : 0;
+    }
+  }
+  // one chunk: FH_KS k-steps on `bc` with the next chunk's B values fetched into `bn` between them, and the tile's
+  // epilogue after its last chunk
+  auto chunk = [&](float (&bc)[FH_KS], float (&bn)[FH_KS]) {
+    const bool last_ch = ch + 1 == nch;
+    const long long ntile = last_ch ? tile + stride : tile;
+    const int nchk = last_ch ? 0 : ch + 1;
+    // source of the prefetch; after the wave's last chunk: a harmless re-read of the chunk in hand.  Past C / 2 the
+    // last channel pair of the SAME pixel is re-read and meets zero weights (no select on the loaded value: it
+    // would make the wave wait for the load here instead of a chunk later).
+    const bool more = ntile < total;
+    const float *xq = b_ptr(more ? ntile : tile, more ? nchk : ch);
+    const int nv = min(FH_KS, C / 2 - (more ? nchk : ch) * FH_KS);
+    if (ch == 0) {
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    }
+    const float *wp = wl + (size_t)(((ch * FH_KS) * 2 + half) * 32 + i) * T;
+    // A operands run one k-step ahead of the matrix instructions that use them (few waves per SIMD: an LDS read
+    // issued behind a group of matrix instructions would only start when the last of them issues)
+    f4 ae[T / 4], ao[T / 4];  // even / odd k-steps: two live register sets, so a read can be issued a step early
+    auto lds_a = [&](int s2, f4(&a)[T / 4]) {
+#pragma unroll
+      for (int t4 = 0; t4 < T / 4; ++t4) a[t4] = *(const f4 *)(wp + s2 * 64 * T + 4 * t4);
+    };
+    auto mfma_step = [&](const f4(&a)[T / 4], float bv) {
+#pragma unroll
+      for (int t4 = 0; t4 < T / 4; ++t4) {
+        acc[4 * t4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t4].x, bv, acc[4 * t4], 0, 0, 0);
+        acc[4 * t4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t4].y, bv, acc[4 * t4 + 1], 0, 0, 0);
+        acc[4 * t4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t4].z, bv, acc[4 * t4 + 2], 0, 0, 0);
+        acc[4 * t4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t4].w, bv, acc[4 * t4 + 3], 0, 0, 0);
+      }
+    };
+    lds_a(0, ae);
+#pragma unroll
+    for (int s2 = 0; s2 < FH_KS; s2 += 2) {
+      // full scheduling fences: left alone, the scheduler sinks each read to just above the instructions that use it
+      lds_a(s2 + 1, ao);
+      bn[s2] = __builtin_nontemporal_load(xq);
+      xq += s2 + 1 < nv ? hw2 : 0;
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(ae, bc[s2]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s2 + 2 < FH_KS) lds_a(s2 + 2, ae);
+      bn[s2 + 1] = __builtin_nontemporal_load(xq);
+      xq += s2 + 2 < nv ? hw2 : 0;
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(ao, bc[s2 + 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (last_ch) {
+      const int n = (int)(tile / tiles_per_img), p0 = (int)(tile - (long long)n * tiles_per_img) * 32;
+      const int p = min(p0 + i, hw - 1);
+      const bool pok = p0 + i < hw;
+      // lane (pixel j = i, half) holds channels d = 32 t + 8 q + 4 half + c, q, c = 0..3  (acc[t][4 q + c])
+      float n2 = 0.0f;
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) n2 = fmaf(acc[t][r], acc[t][r], n2);
+      n2 += __shfl_xor(n2, 32);
+      const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);  // F.normalize(p=2, dim=1, eps=1e-12)
+      float *op = feat + ((size_t)n * hw + p) * D + 4 * half;
+      float best = -INFINITY;
+      for (int k = 0; k < (clu ? K : 0); ++k) {
+        const float *ck = cbank + (size_t)k * D + 4 * half;
+        float dsum = 0.0f;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f4 cv = *(const f4 *)(ck + 32 * t + 8 * q);
+            dsum = fmaf(acc[t][4 * q] * inv, cv.x, dsum); dsum = fmaf(acc[t][4 * q + 1] * inv, cv.y, dsum);
+            dsum = fmaf(acc[t][4 * q + 2] * inv, cv.z, dsum); dsum = fmaf(acc[t][4 * q + 3] * inv, cv.w, dsum);
+          }
+        dsum += __shfl_xor(dsum, 32);
+        best = fmaxf(best, dsum);
+      }
+      if (pok) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *(f4 *)(op + 32 * t + 8 * q) = f4{acc[t][4 * q] * inv, acc[t][4 * q + 1] * inv, acc[t][4 * q + 2] * inv, acc[t][4 * q + 3] * inv};
+        if (clu && half == 0) clu[(size_t)n * hw + p] = best;
+      }
+    }
+    tile = ntile;
+    ch = nchk;
+  };
+  while (tile < total) {
+    chunk(b0, b1);
+    if (tile >= total) break;
+    chunk(b1, b0);
+  }
+}
+
+// Clutter score: out[p] = max_k <cbank[k], feat[p]> (code/MeshPoseSolveAll.py:220,
+// lib/MeshUtils.py:273-275) on the fp32 MFMA (v_mfma_f32_32x32x2_f32, exact f32
+// fmaf chain).  A = 32 clutter vectors, B = 32 pixels, so a lane owns one pixel
+// column and the max over clutter vectors is a max over its accumulators.
+// Lane (i = l & 31, half = l >> 5) feeds feature index 8q + 4*half + c as k-step
+// 4q + c: both operands are then plain 16-byte reads.
+// Persistent workgroups.  The bank goes through LDS in chunks of CK_ROWS vectors (rows padded by four floats: the
+// 16-byte reads of a wave are conflict-free), double-buffered when there is more than one chunk, so the A operand
+// never shares the in-order vector-memory counter with the feature rows; every wave keeps the 32 feature rows of
+// its tile in registers and fetches the rows of its NEXT tile into a second register set under the matrix
+// instructions of the last chunk (without it the waves of a SIMD load together and multiply together: time =
+// stream time + matrix time, 65 TFLOP/s at K = 64; now 104, and 141 = 0.90 of the fp32 matrix peak at K = 2560,
+// tools/time_clutter.py).  Rows past K repeat row K - 1, which leaves the max alone.
+constexpr int CK_ROWS = 64;
+template <int D> struct CkCfg { static constexpr int NT = D <= 128 ? 512 : 256; };  // registers per wave: 256 / 512
+template <int D>
+__global__ __launch_bounds__(CkCfg<D>::NT) void clutter_kernel(const float *__restrict__ feat, size_t npix,
+                                                               const float *__restrict__ cbank, int K,
+                                                               float *__restrict__ out) {
+  constexpr int NT = CkCfg<D>::NT, NWV = NT / 64;
+  constexpr int RS = D + 4;                       // padded row stride in floats
+  constexpr int NS = CK_ROWS * (D / 4) / NT;      // 16-byte pieces of a chunk per thread
+  extern __shared__ __align__(16) float cl[];     // [2][CK_ROWS][RS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, half = lane >> 5;
+  const int nchunks = (K + CK_ROWS - 1) / CK_ROWS;
+  const size_t ntiles = (npix + 31) / 32;
+  f4 st[NS];
+  auto stage_load = [&](int c) {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      const int idx = tid + j * NT, row = idx / (D / 4), col4 = idx - row * (D / 4);
+      st[j] = ((const f4 *)cbank)[(size_t)min(c * CK_ROWS + row, K - 1) * (D / 4) + col4];
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      const int idx = tid + j * NT, row = idx / (D / 4), col4 = idx - row * (D / 4);
+      *(f4 *)(cl + (size_t)buf * CK_ROWS * RS + row * RS + 4 * col4) = st[j];
+    }
+  };
+  auto load_x = [&](size_t tile, f4(&x)[D / 8]) {
+    const size_t pix = min(tile * 32 + (size_t)i, npix - 1);
+    const f4 *xp = (const f4 *)(feat + pix * D) + half;
+#pragma unroll
+    for (int q = 0; q < D / 8; ++q) x[q] = __builtin_nontemporal_load(xp + 2 * q);
+  };
+  const size_t stride = (size_t)gridDim.x * NWV;
+  size_t base = (size_t)blockIdx.x * NWV;  // the workgroup's first tile of the round; every wave takes part in every
+  if (base >= ntiles) return;              // round (barriers), waves past the end recompute the last tile and write nothing
+  f4 xa[D / 8], xb[D / 8];
+  stage_load(0);
+  load_x(min(base + wave, ntiles - 1), xa);
+  stage_store(0);
+  __syncthreads();
+  int buf = 0;
+  auto round = [&](f4(&xc)[D / 8], f4(&xn)[D / 8]) {
+    const size_t tile = base + wave;
+    const size_t nbase = base + stride;
+    float best = -INFINITY;
+    for (int c = 0; c < nchunks; ++c) {
+      if (c + 1 == nchunks) load_x(min((nbase < ntiles ? nbase : base) + wave, ntiles - 1), xn);
+      if (nchunks > 1) stage_load(c + 1 == nchunks ? 0 : c + 1);
+      const float *ap = cl + (size_t)buf * CK_ROWS * RS + i * RS + 4 * half;
+      // rows i (and, when the chunk holds more than 32 vectors, 32 + i) of the chunk against the tile's 32 pixels;
+      // the A operands are read one step ahead of the matrix instructions that use them
+      auto contract = [&](auto two_tag) {
+        constexpr bool TWO = decltype(two_tag)::value;
+        f16v acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+        f4 e0, e1, o0, o1;
+        e0 = *(const f4 *)(ap);
+        if (TWO) e1 = *(const f4 *)(ap + 32 * RS);
+        auto mm = [&](const f4 &a0, const f4 &a1, const f4 &xv) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, xv.x, acc0, 0, 0, 0);
+          if (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, xv.x, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, xv.y, acc0, 0, 0, 0);
+          if (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, xv.y, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, xv.z, acc0, 0, 0, 0);
+          if (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, xv.z, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, xv.w, acc0, 0, 0, 0);
+          if (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, xv.w, acc1, 0, 0, 0);
+        };
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < D / 8; q += 2) {
+          o0 = *(const f4 *)(ap + 8 * (q + 1));
+          if (TWO) o1 = *(const f4 *)(ap + 32 * RS + 8 * (q + 1));
+          __builtin_amdgcn_sched_barrier(0);
+          mm(e0, e1, xc[q]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (q + 2 < D / 8) {
+            e0 = *(const f4 *)(ap + 8 * (q + 2));
+            if (TWO) e1 = *(const f4 *)(ap + 32 * RS + 8 * (q + 2));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          mm(o0, o1, xc[q + 1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) best = fmaxf(best, TWO ? fmaxf(acc0[r], acc1[r]) : acc0[r]);
+      };
+      if (K - c * CK_ROWS > 32) contract(std::true_type{}); else contract(std::false_type{});
+      if (nchunks > 1) {
+        stage_store(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+      }
+    }
+    best = fmaxf(best, __shfl_xor(best, 32));
+    if (half == 0 && tile < ntiles && tile * 32 + i < npix) out[tile * 32 + i] = best;
+    base = nbase;
+  };
+  while (base < ntiles) {
+    round(xa, xb);
+    if (base >= ntiles) break;
+    round(xb, xa);
+  }
+}
+
+// Clutter score for a small bank (K <= 8; the reference's mean clutter vector is K = 1, code/MeshPoseSolveAll.py:207):
+// a matrix-core tile would be all padding, and the pass is a pure stream of the feature maps.  D/8 lanes per pixel
+// read the pixel's row as two coalesced 16-byte loads per lane (all rows of a wave's 8 iterations in flight at once),
+// the clutter vectors come from L1, and a DPP tree reduces each dot product.
+template <int D>
+__global__ __launch_bounds__(256) void clutter_dot_kernel(const float *__restrict__ feat, size_t npix,
+                                                          const float *__restrict__ cbank, int K,
+                                                          float *__restrict__ out) {
+  constexpr int LPP = D / 8, GPW = 64 / LPP, IT = 8;
+  const int lane = threadIdx.x & 63, gl = lane & (LPP - 1), grp = lane / LPP;
+  const size_t p0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (GPW * IT) + grp;
+  f4 x0[IT], x1[IT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const size_t p = p0 + (size_t)it * GPW;
+    const f4 *xp = (const f4 *)(feat + (p < npix ? p : npix - 1) * D) + gl;
+    x0[it] = __builtin_nontemporal_load(xp);
+    x1[it] = __builtin_nontemporal_load(xp + LPP);
+  }
+  float best[IT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) best[it] = -INFINITY;
+  for (int k = 0; k < K; ++k) {
+    const f4 *cp = (const f4 *)(cbank + (size_t)k * D) + gl;
+    const f4 c0 = cp[0], c1 = cp[LPP];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const f4 a = __builtin_elementwise_fma(x1[it], c1, x0[it] * c0);
+      best[it] = fmaxf(best[it], sum_group<LPP>((a.x + a.y) + (a.z + a.w)));
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const size_t p = p0 + (size_t)it * GPW;
+    if (gl == 0 && p < npix) out[p] = best[it];
+  }
+}
+
+}  // namespace
+
+#endif  // MATRIX_KERNELS_HPP

@@ -117,7 +117,7 @@ def test_engine_fails_loudly_without_gpu():
 
 def test_pixel_range_estimates_are_within_three_probes():
     """The kernels settle 'first / last pixel centre inside [vmin, vmax]' with three probes of the
-    PixToNdc table around a closed-form estimate instead of a search loop (nemo_hip.hip, exact_range).
+    PixToNdc table around a closed-form estimate instead of a search loop (nemo_amd/csrc/eval_pose.hpp, exact_range).
     That is exact iff the float32 estimates floor(f), ceil(f), f = ((v + 1) * S - 1) / 2, are within
     [0, +2] resp. [-2, 0] of the true indices: checked here over many raster sizes, including values
     one ulp either side of every pixel centre."""
