@@ -298,15 +298,33 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
   const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
   return (r0 + r1) + (r2 + r3);
 }
+// Min / max over the 64 lanes: DPP inside rows of 16 (no LDS round trips), then the four row results.
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-  return v;
+  v = fminf(v, dpp_mov<0xB1>(v)); v = fminf(v, dpp_mov<0x4E>(v));
+  v = fminf(v, dpp_mov<0x141>(v)); v = fminf(v, dpp_mov<0x140>(v));
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return fminf(fminf(r0, r1), fminf(r2, r3));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+  v = fmaxf(v, dpp_mov<0xB1>(v)); v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v)); v = fmaxf(v, dpp_mov<0x140>(v));
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+// Inclusive prefix sum over the 64 lanes: Hillis-Steele inside rows of 16 with row_shr (lanes shifted in from outside
+// the row read 0), then the three row totals are added to the rows after them.
+template <int CTRL>
+__device__ __forceinline__ int dpp_shr0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+__device__ __forceinline__ int wave_scan_incl(int v, int lane) {
+  v += dpp_shr0<0x111>(v); v += dpp_shr0<0x112>(v); v += dpp_shr0<0x114>(v); v += dpp_shr0<0x118>(v);
+  const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
+  return v + (lane >= 16 ? t0 : 0) + (lane >= 32 ? t1 : 0) + (lane >= 48 ? t2 : 0);
 }
 
 // ---------------------------------------------------------------- phase stamps

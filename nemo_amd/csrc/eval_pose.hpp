@@ -18,6 +18,9 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
 #ifndef NEMO_KIT
 #define NEMO_KIT 2
 #endif
+#ifndef NEMO_PHASEA_MFMA
+#define NEMO_PHASEA_MFMA 0  // 1: phase A on v_mfma_f32_16x16x4_f32 (diagnostic build; measured slower, profiles/r03_solve_kernel_variants.md)
+#endif
   constexpr int KIT = NEMO_KIT;             // 16-byte loads per row per lane
   constexpr int LPP = D / (4 * KIT);        // lanes per pixel: 16 (D=128) or 32 (D=256)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: everything derived from it lives in SGPRs
@@ -144,24 +147,13 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       // all its chunks, reduces them across lanes once (fixed DPP tree) and leaves them in L.red; the
       // split of the list over the waves is a function of its length only, so the totals are
       // reproducible bit for bit.
-      constexpr int GPW = 64 / LPP;
       constexpr int NP = GRAD ? 13 : 1;  // partials per chunk: loss term, dL/dR (9), dL/dT (3)
-      const int gl = lane & (LPP - 1), grp = lane / LPP;
 #ifdef NEMO_STAMPS
       st_score0 = __builtin_amdgcn_s_memrealtime();
 #endif
-      uint4 *rec = (uint4 *)L.zb + wave * CH;                               // [NW][CH]   (the z-buffer is dead by now
-      float *gbuf = (float *)((uint4 *)L.zb + NW * CH) + wave * (CH * 3);   // [NW][CH*3]  and hosts the wave-private scratch)
       // rows are addressed as uniform base + 32-bit byte offset (feature window and bank are < 4 GiB)
       typedef const __attribute__((address_space(1))) char *gbytep;
       const gbytep fbytes = (gbytep)gfeat, bbytes = (gbytep)bank;
-      const uint32_t gl16 = (uint32_t)gl * 16u;
-      // byte offset of the feature row of this lane group's first entry in the chunk [cb_, cb_ + cn_)
-      auto first_off_at = [&](int cb_, int cn_) {
-        const int per_ = (cn_ + GPW - 1) / GPW;
-        return (L.list[cb_ + min(grp * per_, cn_ - 1)] & 0xffffu) * (uint32_t)(D * 4) + gl16;
-      };
-      f4 xa[KIT], xb[KIT];  // ping-pong: current / next feature-row fragments
       // Static split: wave w owns the contiguous entries [ntot w / NW, ntot (w + 1) / NW) and walks them in
       // chunks of CH; its 13 sums stay in registers across chunks and are reduced across lanes once.
       const int seg_b = (ntot * wave) / NW, seg_e = (ntot * (wave + 1)) / NW;
@@ -169,21 +161,141 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       float GR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       float GT[3] = {0.f, 0.f, 0.f};
       int cb = seg_b;
+#if NEMO_PHASEA_MFMA
+      // wave-private scratch in the (dead) z-buffer region, WS_BYTES per wave: per-entry words, per-tile run tables,
+      // the phase A -> B hand-off buffer and a dump row for the lanes that have nothing to hand off
+      static_assert(CH == 64, "the matrix-core phase A works on chunks of 64 entries (4 tiles = 4 DPP rows)");
+      constexpr int WS_BYTES = CH * (12 + 16);
+      unsigned char *wsb = (unsigned char *)L.zb + wave * WS_BYTES;
+      uint32_t *pixw = (uint32_t *)wsb;                    // [64]  (window pixel << 4) | run index inside the tile
+      us4 *trow = (us4 *)(wsb + 256);                      // [4][16] vertex ids of run r of tile t
+      float *gbuf = (float *)(wsb + 768);                  // [64][3] dot products by vertex slot
+      float *dump = (float *)(wsb + 1536);                 // [64]
+      const int pj = lane & 15, kk = lane >> 4;            // operand roles: pixel / row slot pj of the tile, k-group kk
+      const int slot_run = pj / 3, slot_v = pj - 3 * slot_run;  // row slot pj = vertex slot_v of the pass's run slot_run
+#else
+      constexpr int GPW = 64 / LPP;
+      const int gl = lane & (LPP - 1), grp = lane / LPP;
+      uint4 *rec = (uint4 *)L.zb + wave * CH;                               // [NW][CH]   (the z-buffer is dead by now
+      float *gbuf = (float *)((uint4 *)L.zb + NW * CH) + wave * (CH * 3);   // [NW][CH*3]  and hosts the wave-private scratch)
+      const uint32_t gl16 = (uint32_t)gl * 16u;
+      // byte offset of the feature row of this lane group's first entry in the chunk [cb_, cb_ + cn_)
+      auto first_off_at = [&](int cb_, int cn_) {
+        const int per_ = (cn_ + GPW - 1) / GPW;
+        return (L.list[cb_ + min(grp * per_, cn_ - 1)] & 0xffffu) * (uint32_t)(D * 4) + gl16;
+      };
+      f4 xa[KIT], xb[KIT];  // ping-pong: current / next feature-row fragments
       if (cb < seg_e) {
         const gf4p Fp = (gf4p)(fbytes + first_off_at(cb, min(CH, seg_e - cb)));
 #pragma unroll
         for (int k = 0; k < KIT; ++k) xa[k] = __builtin_nontemporal_load(Fp + LPP * k);
       }
+#endif
       while (cb < seg_e) {
         const int cn = min(CH, seg_e - cb);
         const int cb_next = cb + CH;
+        uint32_t ent_bs[CH / 64];
+        float cls[CH / 64];
+#if NEMO_PHASEA_MFMA
+        // ---------------- records (one lane per entry; a tile = 16 consecutive entries = one DPP row).  The list is
+        // face-major, so a tile is a few runs of equal face: lane e finds the run it belongs to (head flags, row
+        // scan), run heads publish their three vertex ids, every lane its pixel and run index.
+        int nrun_t[4];  // runs per tile (wave-uniform)
+        {
+          const uint32_t ent = L.list[cb + min(lane, cn - 1)];  // lanes past the end repeat the last entry
+          ent_bs[0] = ent;
+          cls[0] = (P.clutter && clu) ? gclu[ent & 0xffffu] : 0.0f;
+          const int f = (int)(ent >> 16);
+          const us4 fv_ = fc_at<BIG>(L, f);
+          const int fprev = __builtin_amdgcn_update_dpp(-1, f, 0x111, 0xF, 0xF, false);  // row_shr:1; lane 0 of a row keeps -1
+          const int head = (int)(f != fprev);
+          int rho = head;
+          rho += dpp_shr0<0x111>(rho); rho += dpp_shr0<0x112>(rho); rho += dpp_shr0<0x114>(rho); rho += dpp_shr0<0x118>(rho);
+          rho -= 1;  // run index inside the tile, 0 .. 15
+          if (head) trow[(lane >> 4) * 16 + rho] = fv_;
+          pixw[lane] = ((ent & 0xffffu) << 4) | (uint32_t)rho;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) nrun_t[t] = __builtin_amdgcn_readlane(rho, 16 * t + 15) + 1;
+        }
+        // ---------------- phase A on the matrix cores: per tile, D[row slot][pixel] = bank rows x feature rows with
+        // v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains).  Lane (pj, kk) feeds feature 16 q + 4 kk + c as k-step
+        // 4 q + c of BOTH operands, so both are plain 16-byte loads: 8 per feature row (all 16 rows of the tile in
+        // flight at once) and 8 per bank row.  A pass holds the rows of 5 runs (3 vertices each; slot 15 idle); a
+        // tile with more runs takes further passes over the same feature registers.  Lane (pj, kk) ends up with the
+        // products of pixel pj against row slots 4 kk .. 4 kk + 3 and hands those its pixel needs to phase B.
+        {
+          const int ntile = (cn + 15) >> 4;
+          for (int t = 0; t < ntile; ++t) {
+            const uint32_t w = pixw[16 * t + pj];
+            const int nr = t == 0 ? nrun_t[0] : (t == 1 ? nrun_t[1] : (t == 2 ? nrun_t[2] : nrun_t[3]));
+#ifndef NEMO_MF_LINE
+#define NEMO_MF_LINE 0
+#endif
+#ifndef NEMO_MF_NT
+#define NEMO_MF_NT 1
+#endif
+#ifndef NEMO_MF_ABL
+#define NEMO_MF_ABL 0
+#endif
+            // k-step 4 q + c of a lane is feature 16 q + 4 kk + c (LINE 0: the four k-groups of a row share 64-byte
+            // segments) or 32 kk + 4 q + c (LINE 1: a lane walks one 128-byte line of its row)
+            constexpr int KK_B = NEMO_MF_LINE ? 128 : 16, Q_F4 = NEMO_MF_LINE ? 1 : 4;
+            const uint32_t foff = (w >> 4) * (uint32_t)(D * 4) + (uint32_t)kk * KK_B;
+            const int my_run = (int)(w & 15u);
+            const int ent_i = 16 * t + pj;
+            f4 xf[8], yb[8];
+            if (D == 128) {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) xf[q] = (NEMO_MF_ABL == 2) ? f4{1.f, 1.f, 1.f, 1.f} : (NEMO_MF_NT ? __builtin_nontemporal_load((gf4p)(fbytes + foff) + Q_F4 * q) : ((gf4p)(fbytes + foff))[Q_F4 * q]);
+            }
+            for (int r0 = 0; r0 < nr; r0 += 5) {
+              const us4 rv = trow[t * 16 + min(r0 + slot_run, nr - 1)];
+              const uint32_t vid = slot_v == 0 ? rv.x : (slot_v == 1 ? rv.y : rv.z);
+              const uint32_t boff = vid * (uint32_t)(D * 4) + (uint32_t)kk * KK_B;
+              f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int hh = 0; hh < D / 128; ++hh) {
+                if (D != 128) {
+#pragma unroll
+                  for (int q = 0; q < 8; ++q) xf[q] = __builtin_nontemporal_load((gf4p)(fbytes + foff) + (NEMO_MF_LINE ? 32 * hh + q : 32 * hh + 4 * q));
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) yb[q] = (NEMO_MF_ABL == 3) ? f4{1.f, 1.f, 1.f, 1.f} : ((gf4p)(bbytes + boff))[NEMO_MF_LINE ? 32 * hh + q : 32 * hh + 4 * q];
+                if (NEMO_MF_ABL == 1) {
+#pragma unroll
+                  for (int q = 0; q < 8; ++q) acc0 += yb[q] * xf[q];
+                } else
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) {
+                  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(yb[q].x, xf[q].x, acc0, 0, 0, 0);
+                  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(yb[q + 1].x, xf[q + 1].x, acc1, 0, 0, 0);
+                  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(yb[q].y, xf[q].y, acc0, 0, 0, 0);
+                  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(yb[q + 1].y, xf[q + 1].y, acc1, 0, 0, 0);
+                  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(yb[q].z, xf[q].z, acc0, 0, 0, 0);
+                  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(yb[q + 1].z, xf[q + 1].z, acc1, 0, 0, 0);
+                  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(yb[q].w, xf[q].w, acc0, 0, 0, 0);
+                  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(yb[q + 1].w, xf[q + 1].w, acc1, 0, 0, 0);
+                }
+              }
+              const f4 acc = acc0 + acc1;
+              // hand-off: row slot 4 kk + r holds vertex (4 kk + r) - 3 rel of the pixel's run when that is 0, 1 or 2
+              const int rel = my_run - r0;
+              const bool mine = rel >= 0 && rel < 5 && ent_i < cn;
+              const int v0 = 4 * kk - 3 * rel;  // vertex index of my register 0
+              float *gb = gbuf + 3 * ent_i;
+              *((mine && (unsigned)(v0 + 0) < 3u) ? gb + v0 + 0 : dump + lane) = acc.x;
+              *((mine && (unsigned)(v0 + 1) < 3u) ? gb + v0 + 1 : dump + lane) = acc.y;
+              *((mine && (unsigned)(v0 + 2) < 3u) ? gb + v0 + 2 : dump + lane) = acc.z;
+              *((mine && (unsigned)(v0 + 3) < 3u) ? gb + v0 + 3 : dump + lane) = acc.w;
+            }
+          }
+        }
+#else
         const int per = (cn + GPW - 1) / GPW;  // entries per lane group in this chunk
         // ---------------- records (one lane per entry): everything phase A needs to know about an entry
         // -- feature-row byte offset and the three bank rows -- is worked out once here, 64 entries per
         // instruction, instead of by every lane of a group inside the loop.  The same pass fetches this
         // lane's phase-B list entries and clutter scores (they land during phase A).
-        uint32_t ent_bs[CH / 64];
-        float cls[CH / 64];
 #pragma unroll
         for (int u = 0; u < CH / 64; ++u) {
           const uint32_t ent = L.list[cb + min(u * 64 + lane, cn - 1)];
@@ -274,6 +386,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
             for (int k = 0; k < KIT; ++k) xa[k] = xb[k];
           }
         }
+#endif
         STAMP(8);
         // ---------------- phase B: this lane's pixels -> its 13 contributions
 #pragma unroll
@@ -559,12 +672,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
             for (int a = fa_lo; a <= fa_hi; ++a) cnt += (int)(zface(a, b) == (uint32_t)f);
         }
       }
-      int incl = cnt;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int y = __shfl_up(incl, o);
-        if (lane >= o) incl += y;
-      }
+      const int incl = wave_scan_incl(cnt, lane);
       int *ired = (int *)L.red;
       if (lane == 63) ired[wave * RED_N + 8] = incl;
       __syncthreads();
