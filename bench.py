@@ -74,6 +74,75 @@ def cpu_baseline(wl, n_sample):
                       f'hand-derived backward, which is faster than the torch-autograd op sequence of the reference'}
 
 
+def cpu_baseline_autograd(n_proc, steps=8):
+    """SURVEY 8(d)'s CPU baseline: the reference's own op sequence (look-at -> transform -> naive all-faces-per-pixel
+    raster over the full S x S square -> gather-interpolate -> crop -> mul/sum -> loss -> torch.autograd backward ->
+    torch.optim.Adam, code/MeshPoseSolveAll.py:235-250) on BASELINE configs[0]'s image (car, 640x800, V = 1088), one
+    single-threaded worker PROCESS per host core, all at the same time (InferenceNeMo.sh:67-78 runs one process per
+    category).  Each worker (oracle/ref_sequence.py, checker-side code) times `steps` Adam steps, 16 cached-grid
+    evaluations and 4 pre-renders; a solve is EXTRAPOLATED from those as 300 steps + 144 grid evaluations + 144/16
+    pre-renders.  PyTorch3D's native rasteriser is stood in for by the oracle's C restatement of it."""
+    env = dict(os.environ, OMP_NUM_THREADS='1', MKL_NUM_THREADS='1', HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+    env['PYTHONPATH'] = ROOT + os.pathsep + env.get('PYTHONPATH', '')
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, '-m', 'oracle.ref_sequence', '--steps', str(steps), '--seed', str(100 + k)],
+                              cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k in range(n_proc)]
+    outs = []
+    for pr in procs:
+        try:
+            so, se = pr.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            so, se = pr.communicate()
+        if pr.returncode == 0 and so.strip():
+            outs.append(json.loads(so.strip().splitlines()[-1]))
+    dt = time.perf_counter() - t0
+    if not outs:
+        return {'error': 'no worker finished', 'cores': n_proc}
+    solve_s = float(np.mean([o['solve_s_extrapolated'] for o in outs]))
+    return {'value': len(outs) / solve_s, 'unit': 'solves/s', 'cores': len(outs), 'per_core': 1.0 / solve_s, 'kind': 'port',
+            'extrapolated': True, 'solve_s_per_image_per_core': solve_s,
+            'ms_per_adam_step': 1e3 * float(np.mean([o['t_step_s'] for o in outs])),
+            'ms_per_cached_grid_evaluation': 1e3 * float(np.mean([o['t_grid_eval_s'] for o in outs])),
+            'ms_per_prerender': 1e3 * float(np.mean([o['t_prerender_s'] for o in outs])),
+            'sample': f"BASELINE configs[0]'s image (car, 640x800, 100x100 raster, V = 1088, F = 1844, D = 128): {len(outs)} "
+                      f'single-threaded worker processes at once (torch.set_num_threads(1)), each timing {steps} Adam steps of the '
+                      f"reference's op sequence with torch.autograd + torch.optim.Adam, 16 cached-grid evaluations and 4 pre-renders; "
+                      f'one solve = 300 steps + 144 evaluations + 144/16 pre-renders EXTRAPOLATED from those; {dt:.1f} s wall; '
+                      f'host has {os.cpu_count()} logical CPUs.  The rasteriser is the C restatement of '
+                      f"PyTorch3D's naive CPU loop (PyTorch3D itself cannot run here)"}
+
+
+MFMA_FP32_PEAK_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+
+
+def roofline_mfma(eng, feats, K=2560, reps=3):
+    """The path's matrix-core contraction, timed on its own (never part of `value`): clutter_kernel = pixels x clutter
+    bank, max over the bank (lib/MeshUtils.py:273-275), on the bench's resident maps against a bank of the reference's
+    size, K = num_noise * max_group = 5 * 512 = 2560 (TrainNeMo.sh:24-25).  flops = 2 h w D K per image."""
+    from nemo_amd import synthetic as syn
+    bank = torch.as_tensor(syn.unit_rows(np.random.default_rng(7), K, eng.D)).to(eng.device).contiguous()
+    eng.clutter_score(feats, bank)
+    torch.cuda.synchronize(eng.device)
+    evs = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        eng.clutter_score(feats, bank)
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize(eng.device)
+    ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    n = feats.shape[0]
+    flops = 2.0 * eng.h * eng.w * eng.D * K * n
+    tf = flops / (ms * 1e-3) / 1e12
+    return {'bound': 'mfma', 'achieved': tf, 'peak': MFMA_FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / MFMA_FP32_PEAK_TFLOPS,
+            'traffic': None, 'kernel': 'clutter_kernel', 'kernel_ms': ms, 'flops_per_launch': flops, 'dtype': 'f32',
+            'config': {'images': int(n), 'feature_map': [eng.h, eng.w, eng.D], 'clutter_vectors': K},
+            'note': 'separate from `value`: the bench workload scores clutter with the reference\'s one mean vector (K = 1, a '
+                    'streaming kernel); this block runs the K-vector contraction of the same maps on the fp32 matrix cores'}
+
+
 def from_files_leg(n_images, dev, batch):
     """The file-driven entry (python -m nemo_amd.solve_all = the reference's code/MeshPoseSolveAll.py:173,217-219:
     feature .npz + CAD .off in, poses out) on a synthetic one-category record of `n_images` car images, written to a
@@ -178,7 +247,7 @@ def launch_ranks(n_gpus, argv):
     return subprocess.call(cmd, env=env)
 
 
-PMC_FILE = 'profiles/r02_pmc_traffic.json'
+PMC_FILE = 'profiles/r03_pmc_traffic.json'
 
 
 def pmc_traffic(cov_steps):
@@ -312,6 +381,8 @@ def main():
                          'infinity_cache_bytes': 256 * 2 ** 20},
             'quality': {'finite_fraction': ok, 'median_err_deg_vs_synthetic_gt': float(np.degrees(np.median(errs)))},
         }
+        if world == 1:
+            out['roofline_mfma'] = roofline_mfma(eng, wl.feats)
         if world == 1 and args.from_files_images > 0:
             del res
             ff = from_files_leg(args.from_files_images, dev, args.from_files_batch)
@@ -321,6 +392,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             n_sample = args.cpu_sample or 3 * min(16, os.cpu_count() or 1)
             out['cpu_baseline'] = cpu_baseline(wl, n_sample)
+            out['cpu_baseline_autograd'] = cpu_baseline_autograd(min(16, os.cpu_count() or 1))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

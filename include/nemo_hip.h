@@ -165,7 +165,9 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
  * workgroup per job; schedule from nemo_set_schedule.  d_pose f32[N][4]
  * = final (Cx,Cy,Cz,theta), d_loss f32[N] = loss at the last evaluated iterate,
  * d_trace f32[N][steps][9] = (C, theta, loss, gC, gtheta) at the start of every
- * step, or NULL.
+ * step, or NULL.  d_status i32[N] or NULL: 1 = the job's final pose is finite, 0 = it is not (a non-finite start
+ * pose stays non-finite; the launch completes and the other jobs are unaffected) -- the per-image flag behind the
+ * reference's "NaN / Inf -> error pi/2" rule (code/MeshPoseSolveAll.py:262-263).
  * Scheduling (results do not depend on it): for N > 64 the jobs are started longest first -- one
  * rasterisation per job counts the pixels covered at (C0, theta0), a device counting sort orders the job
  * ids, workgroup b runs job order[b]; the int32[2N] workspace comes from nemo_workspace_reserve
@@ -175,26 +177,32 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
  * in index order, NEMO_SOLVE_AFFINITY=0 skips the XCD pass. */
 int nemo_solve(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t *d_mesh_idx,
                const float *d_feat, const float *d_clu, const float *d_C0, const float *d_theta0,
-               float *d_pose, float *d_loss, float *d_trace, void *stream);
+               float *d_pose, float *d_loss, float *d_trace, int32_t *d_status, void *stream);
 
 /* 6-DoF variant of the solve (code/PredUnlabeledDataset.py:318-347): Adam also moves trans_2d, which
  * enters the camera as extra_trans = trans_2d @ [[1,0,0],[0,1,0]] added to T (:328, lib/MeshUtils.py:107-108).
  * Same kernel as nemo_solve.  d_trans0 f32[N][2] (NULL = zeros, :318); d_pose6 f32[N][6] =
- * (Cx,Cy,Cz,theta,t0,t1); d_trace f32[N][steps][13] = (p6, loss, g6) at the start of every step, or NULL. */
+ * (Cx,Cy,Cz,theta,t0,t1); d_trace f32[N][steps][13] = (p6, loss, g6) at the start of every step, or NULL;
+ * d_status as in nemo_solve (all six components finite). */
 int nemo_solve6(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t *d_mesh_idx,
                 const float *d_feat, const float *d_clu, const float *d_C0, const float *d_theta0,
-                const float *d_trans0, float *d_pose6, float *d_loss, float *d_trace, void *stream);
+                const float *d_trans0, float *d_pose6, float *d_loss, float *d_trace, int32_t *d_status,
+                void *stream);
 
 /* nemo_solve for callers that cannot allocate at all (code under HIP graph capture, tight serving loops, harnesses
  * that forbid hipMalloc).  It has NO counterpart in the reference.  Same arguments and results as nemo_solve (bit
  * for bit); the launch-order workspace is a file-scope device array of the library (int32[2 * 16384] = 128 KiB per
  * GPU, held until the process ends) instead of the context's reservation, so neither this call nor any set-up for
  * it allocates.  Limits: N <= 16384 (NEMO_ERR_UNSUPPORTED beyond); meshes whose tables do not fit the LDS are
- * refused (their per-workgroup table scratch is far larger than a static array should be).  Every call on a GPU
- * shares that GPU's array: calls that overlap on one GPU (two streams, two contexts) race on it. */
+ * refused (their per-workgroup table scratch is far larger than a static array should be).  With N <= 64 the jobs
+ * are launched in index order and the array is not touched at all.  Every call on a GPU shares that GPU's array:
+ * calls that overlap on one GPU (two streams, two contexts) race on it, and the race corrupts RESULTS, not only the
+ * schedule -- a launch order overwritten by another call makes some jobs run twice and others not at all (their
+ * d_pose / d_loss / d_status rows keep whatever the buffers held); job ids outside [0, N) are dropped, so nothing is
+ * written out of bounds.  Serialise such calls. */
 int nemo_solve_static(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t *d_mesh_idx,
                       const float *d_feat, const float *d_clu, const float *d_C0, const float *d_theta0,
-                      float *d_pose, float *d_loss, float *d_trace, void *stream);
+                      float *d_pose, float *d_loss, float *d_trace, int32_t *d_status, void *stream);
 
 /* Bytes the fused kernels read per covered pixel and step: 4*D + 4. */
 int64_t nemo_bytes_per_covered_pixel(const nemo_ctx *ctx);

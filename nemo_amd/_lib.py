@@ -58,11 +58,11 @@ def load():
     lib.nemo_score_fwd_bwd.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.nemo_grid_search.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     lib.nemo_grid_prerender.argtypes = [vp, vp, vp, i32, i32, vp, vp, i32, vp]
-    lib.nemo_solve.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
-    lib.nemo_solve_static.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.nemo_solve.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.nemo_solve_static.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.nemo_workspace_reserve.argtypes = [vp, i32, i32]
     lib.nemo_feature_head.argtypes = [vp, vp, i32, i32, vp, vp, i32, vp, vp, vp]
-    lib.nemo_solve6.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.nemo_solve6.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.nemo_bytes_per_covered_pixel.restype = C.c_int64
     lib.nemo_bytes_per_covered_pixel.argtypes = [vp]
     lib.nemo_counter_reset.argtypes = [vp, vp]

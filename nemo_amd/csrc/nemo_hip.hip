@@ -154,11 +154,11 @@ static int reserve_big_scratch(nemo_ctx *ctx, size_t nblocks) {
   if (nblocks > ctx->big_blocks_req) ctx->big_blocks_req = nblocks;
   if (!ctx->P.big) return NEMO_OK;
   const size_t need = ctx->big_blocks_req * (size_t)ctx->P.big_stride;
-  if (need > ctx->big_cap) {
+  if (need > ctx->big_cap) {  // the new block first: a failed allocation leaves the old scratch in place
+    unsigned char *nb = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&nb, need));
     hipFree(ctx->d_big);
-    ctx->d_big = nullptr;
-    ctx->big_cap = 0;
-    HIP_TRY(ctx, hipMalloc(&ctx->d_big, need));
+    ctx->d_big = nb;
     ctx->big_cap = need;
   }
   ctx->P.big_scratch = (unsigned long long)(uintptr_t)ctx->d_big;
@@ -431,7 +431,11 @@ int nemo_mesh_register(nemo_ctx *ctx, const float *d_verts, int32_t V, const int
       ctx->vmax_seen = old_vmax; ctx->fmax_seen = old_fmax; plan_lds(ctx);
       return fail(ctx, NEMO_ERR_ARG, "nemo_mesh_register: face %zu refers to vertex %d (V = %d)", k / 3, hf[k], V);
     }
-  if ((rc = reserve_big_scratch(ctx, 0)) != NEMO_OK) return rc;  // the slice size may have grown: re-apply the reservation
+  if ((rc = reserve_big_scratch(ctx, 0)) != NEMO_OK) {  // the slice size may have grown: re-apply the reservation
+    ctx->vmax_seen = old_vmax; ctx->fmax_seen = old_fmax; plan_lds(ctx);  // as the error paths above: the mesh was not registered
+    reserve_big_scratch(ctx, 0);
+    return rc;
+  }
   std::vector<uint8_t> order((size_t)F);
   {
     static const int perms[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
@@ -711,8 +715,8 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
 // static device array; never allocated here.
 static int launch_solve(nemo_ctx *ctx, const char *who, int32_t N, const int32_t *d_img_idx, const int32_t *d_mesh_idx,
                         const float *d_feat, const float *d_clu, const float *d_C0, const float *d_theta0,
-                        const float *d_trans0, int ndof, float *d_pose, float *d_loss, float *d_trace, void *stream,
-                        int32_t *ws, size_t ws_cap) {
+                        const float *d_trans0, int ndof, float *d_pose, float *d_loss, float *d_trace, int32_t *d_status,
+                        void *stream, int32_t *ws, size_t ws_cap) {
   int rc = check_ready(ctx, who, N);
   if (rc) return rc > 0 ? NEMO_OK : rc;
   if (ctx->adam_steps <= 0) return fail(ctx, NEMO_ERR_STATE, "%s: call nemo_set_schedule first", who);
@@ -743,21 +747,21 @@ static int launch_solve(nemo_ctx *ctx, const char *who, int32_t N, const int32_t
   }
   DISPATCH_DP(solve_kernel, dim3(N), ctx->P, ctx->d_meshes, d_img_idx, d_mesh_idx, d_feat, d_clu, d_C0, d_theta0, d_trans0,
               ndof, ctx->d_adam, ctx->adam_steps, ctx->beta1, ctx->beta2, ctx->eps, d_pose, d_loss, d_trace, ctx->d_counter,
-              stagger, d_order);
+              stagger, d_order, (int)N, d_status);
   HIP_TRY(ctx, hipGetLastError());
   return NEMO_OK;
 }
 
 int nemo_solve(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t *d_mesh_idx, const float *d_feat,
                const float *d_clu, const float *d_C0, const float *d_theta0, float *d_pose, float *d_loss,
-               float *d_trace, void *stream) {
+               float *d_trace, int32_t *d_status, void *stream) {
   return launch_solve(ctx, "nemo_solve", N, d_img_idx, d_mesh_idx, d_feat, d_clu, d_C0, d_theta0, nullptr, 4, d_pose,
-                      d_loss, d_trace, stream, ctx ? ctx->d_so : nullptr, ctx ? ctx->so_cap : 0);
+                      d_loss, d_trace, d_status, stream, ctx ? ctx->d_so : nullptr, ctx ? ctx->so_cap : 0);
 }
 
 int nemo_solve_static(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t *d_mesh_idx, const float *d_feat,
                       const float *d_clu, const float *d_C0, const float *d_theta0, float *d_pose, float *d_loss,
-                      float *d_trace, void *stream) {
+                      float *d_trace, int32_t *d_status, void *stream) {
   if (!ctx) return fail(nullptr, NEMO_ERR_ARG, "nemo_solve_static: null ctx");
   if (N > STATIC_MAX_JOBS)
     return fail(ctx, NEMO_ERR_UNSUPPORTED, "nemo_solve_static: %d jobs, the static workspace holds %d", N, STATIC_MAX_JOBS);
@@ -767,14 +771,14 @@ int nemo_solve_static(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const 
   int32_t *ws = (ctx->device >= 0 && ctx->device < MAX_DEVICES) ? g_static_ws[ctx->device] : nullptr;
   if (!ws) return fail(ctx, NEMO_ERR_STATE, "nemo_solve_static: no static workspace on device %d", ctx->device);
   return launch_solve(ctx, "nemo_solve_static", N, d_img_idx, d_mesh_idx, d_feat, d_clu, d_C0, d_theta0, nullptr, 4, d_pose,
-                      d_loss, d_trace, stream, ws, (size_t)STATIC_MAX_JOBS);
+                      d_loss, d_trace, d_status, stream, ws, (size_t)STATIC_MAX_JOBS);
 }
 
 int nemo_solve6(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t *d_mesh_idx, const float *d_feat,
                 const float *d_clu, const float *d_C0, const float *d_theta0, const float *d_trans0, float *d_pose6,
-                float *d_loss, float *d_trace, void *stream) {
+                float *d_loss, float *d_trace, int32_t *d_status, void *stream) {
   return launch_solve(ctx, "nemo_solve6", N, d_img_idx, d_mesh_idx, d_feat, d_clu, d_C0, d_theta0, d_trans0, 6, d_pose6,
-                      d_loss, d_trace, stream, ctx ? ctx->d_so : nullptr, ctx ? ctx->so_cap : 0);
+                      d_loss, d_trace, d_status, stream, ctx ? ctx->d_so : nullptr, ctx ? ctx->so_cap : 0);
 }
 
 int nemo_interpolate_backward(nemo_ctx *ctx, const int32_t *d_mesh_idx, const float *d_R, const float *d_T,

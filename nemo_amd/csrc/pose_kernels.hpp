@@ -284,8 +284,11 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
                                                       int ndof, const float *adam_tab, int steps, float beta1,
                                                       float beta2, float eps, float *pose, float *loss_out,
                                                       float *trace, u64 *counter, int stagger,
-                                                      const int32_t *order) {
+                                                      const int32_t *order, int N, int32_t *status) {
   const int n = order ? order[blockIdx.x] : (int)blockIdx.x;  // longest job first (solve_order_kernel)
+  // `order` is a permutation of [0, N) written by this call's own set-up kernels; a workgroup that reads anything
+  // else (nemo_solve_static's shared array overwritten by an overlapping call) leaves instead of indexing with it
+  if ((unsigned)n >= (unsigned)N) return;
   const MeshDesc M = meshes[mesh_idx ? mesh_idx[n] : 0];
   const int img = img_idx ? img_idx[n] : n;
   const size_t hw = (size_t)P.h * P.w;
@@ -394,6 +397,11 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
     po[0] = L.ust[U_P]; po[1] = L.ust[U_P + 1]; po[2] = L.ust[U_P + 2]; po[3] = L.ust[U_P + 3];
     if (ndof == 6) { po[4] = L.ust[U_P6]; po[5] = L.ust[U_P6 + 1]; }
     if (loss_out) loss_out[n] = last_loss;
+    if (status) {  // 1 = finite pose, 0 = not (scored pi/2 by the evaluation, code/MeshPoseSolveAll.py:262-263)
+      bool ok = true;
+      for (int i = 0; i < ndof; ++i) ok = ok && __builtin_isfinite(po[i]);
+      status[n] = ok ? 1 : 0;
+    }
     if (counter) atomicAdd(counter, cov_total);
   }
 }

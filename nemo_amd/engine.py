@@ -116,8 +116,10 @@ class PoseEngine:
         self._res_cells = max(self._res_cells, int(max_jobs) * int(max_grid_poses))
 
     def _need(self, n_jobs: int, G: int = 0):
+        # the library grows each workspace on its own (launch order by jobs, partial sums by jobs x poses), so the
+        # call's own (N, G) is what to ask for: max(N so far) x this G would over-allocate the partial sums
         if n_jobs > self._res_jobs or n_jobs * G > self._res_cells:
-            self.reserve(max(n_jobs, self._res_jobs), G)
+            self.reserve(n_jobs, G)
 
     def set_schedule(self, steps=300, lr=0.05, betas=(0.4, 0.6), eps=1e-8, decay_every=100, gamma=0.2):
         tab = np.ascontiguousarray(adam_table(steps, lr, betas[0], betas[1], decay_every, gamma))
@@ -305,10 +307,12 @@ class PoseEngine:
                    'nemo_grid_prerender')
         self._pre_keep = (grid_C, grid_theta)  # the store is keyed by these device buffers: keep them alive
 
-    def solve(self, feat, clu, C0, theta0, img_idx=None, mesh_idx=None, want_trace=False, out=None, static=False):
+    def solve(self, feat, clu, C0, theta0, img_idx=None, mesh_idx=None, want_trace=False, out=None, static=False,
+              status=None):
         """nemo_solve.  `out` = (pose [N,4], loss [N]) buffers to fill instead of fresh ones; static=True goes
         through nemo_solve_static (launch-order workspace in the library's static device array: nothing is
-        allocated by the library; with `out` given, nothing by this wrapper either)."""
+        allocated by the library; with `out` given, nothing by this wrapper either).  `status` = int32 [N] buffer
+        for the per-job flag (1 = finite final pose, 0 = not), or None."""
         C0, theta0 = self._f32(C0, 'C0'), self._f32(theta0, 'theta0')
         N = C0.shape[0]
         feat = self._feat(feat)
@@ -321,16 +325,18 @@ class PoseEngine:
             raise ValueError('out: expected (pose [N,4], loss [N])')
         pose, loss = self._f32(pose, 'pose'), self._f32(loss, 'loss')
         trace = self._empty((N, self.steps, 9)) if want_trace else None
+        if status is not None and tuple(self._i32(status, 'status').shape) != (N,):
+            raise ValueError(f'status: expected int32 [{N}]')
         fn, name = (self.lib.nemo_solve_static, 'nemo_solve_static') if static else (self.lib.nemo_solve, 'nemo_solve')
         _lib.check(self.ctx, fn(
             self.ctx, N, _ptr(img_idx), _ptr(mesh_idx),
             _ptr(feat), _ptr(clu), _ptr(C0), _ptr(theta0), _ptr(pose),
-            _ptr(loss), _ptr(trace), self._stream()), name)
+            _ptr(loss), _ptr(trace), _ptr(status), self._stream()), name)
         return (pose, loss, trace) if want_trace else (pose, loss)
 
-    def solve6(self, feat, clu, C0, theta0, trans0=None, img_idx=None, mesh_idx=None, want_trace=False):
+    def solve6(self, feat, clu, C0, theta0, trans0=None, img_idx=None, mesh_idx=None, want_trace=False, status=None):
         """6-DoF solve (code/PredUnlabeledDataset.py:318-347): returns pose6 [N,6] = (C, theta, trans_2d), loss
-        (and the [N,steps,13] trace)."""
+        (and the [N,steps,13] trace); `status` as in solve()."""
         C0, theta0 = self._f32(C0, 'C0'), self._f32(theta0, 'theta0')
         N = C0.shape[0]
         feat = self._feat(feat)
@@ -341,10 +347,12 @@ class PoseEngine:
         self._need(N)
         pose, loss = self._empty((N, 6)), self._empty((N,))
         trace = self._empty((N, self.steps, 13)) if want_trace else None
+        if status is not None and tuple(self._i32(status, 'status').shape) != (N,):
+            raise ValueError(f'status: expected int32 [{N}]')
         _lib.check(self.ctx, self.lib.nemo_solve6(
             self.ctx, N, _ptr(img_idx), _ptr(mesh_idx),
             _ptr(feat), _ptr(clu), _ptr(C0), _ptr(theta0),
-            _ptr(trans0), _ptr(pose), _ptr(loss), _ptr(trace), self._stream()), 'nemo_solve6')
+            _ptr(trans0), _ptr(pose), _ptr(loss), _ptr(trace), _ptr(status), self._stream()), 'nemo_solve6')
         return (pose, loss, trace) if want_trace else (pose, loss)
 
     # ------------------------------------------------------------------ accounting

@@ -299,10 +299,14 @@ class Meshes:
     """Holder with the part of PyTorch3D's Meshes the reference touches (lib/MeshUtils.py:168,176,213,221):
     lists of PRE-PROCESSED vertices and faces, `extend`, `offset_verts`, `to`."""
 
-    def __init__(self, verts, faces, textures=None):
+    def __init__(self, verts, faces, textures=None, _root=None, _map=None):
         self._verts = [torch.as_tensor(v, dtype=torch.float32) for v in verts]
         self._faces = [torch.as_tensor(f) for f in faces]
         self._engines = {}
+        # extend(n) replicates a mesh for n cameras (lib/MeshUtils.py:221); the replicas are the same geometry, so
+        # they are served by the engine of the Meshes they came from: element j renders mesh _map[j] of _root
+        self._root = _root
+        self._map = _map
 
     def __len__(self):
         return len(self._verts)
@@ -317,14 +321,17 @@ class Meshes:
         return torch.cat(self._verts, 0)
 
     def extend(self, n):
-        return Meshes([v for v in self._verts for _ in range(n)], [f for f in self._faces for _ in range(n)])
+        root = self._root if self._root is not None else self
+        base = self._map if self._map is not None else list(range(len(self)))
+        return Meshes([v for v in self._verts for _ in range(n)], [f for f in self._faces for _ in range(n)],
+                      _root=root, _map=[m for m in base for _ in range(n)])
 
     def offset_verts(self, offsets):
         out, start = [], 0
         for v in self._verts:
             out.append(v + offsets[start:start + v.shape[0]].to(v.device))
             start += v.shape[0]
-        return Meshes(out, self._faces)
+        return Meshes(out, self._faces)   # new geometry: its own engine
 
     def to(self, device):
         return Meshes([v.to(device) for v in self._verts], [f.to(device) for f in self._faces])
@@ -334,32 +341,48 @@ class Meshes:
 
 
 def _engine_for(meshes: Meshes, rasterizer: MeshRasterizer, face_memory=None):
-    """One PoseEngine per (Meshes object, raster settings, face memory): rendering the full S x S square, with
-    `face_memory` [sum F, 3, D] presented to the kernels as a bank of 3 F rows indexed by faces (3f, 3f+1, 3f+2)."""
+    """(engine, mesh index per batch element).  ONE PoseEngine per (root Meshes, raster settings, feature width):
+    it renders the full S x S square, with `face_memory` [sum F, 3, D] presented to the kernels as a bank of 3 F rows
+    indexed by faces (3f, 3f+1, 3f+2).  A face memory that changed since the last call (another tensor, or the same
+    one updated in place) is copied into the registered bank -- no new context, no new registration; extend(n)
+    replicas share their root's engine."""
     rs = rasterizer.raster_settings
     if rs.blur_radius != 0 or rs.faces_per_pixel != 1 or rs.bin_size not in (0, None):
         raise NotImplementedError('only blur_radius=0, faces_per_pixel=1, naive rasterization is implemented')
-    key = (int(rs.image_size), float(rasterizer.cameras.fov), bool(getattr(rs, 'perspective_correct', False)),
-           None if face_memory is None else (face_memory.data_ptr(), face_memory._version, tuple(face_memory.shape)))
-    eng = meshes._engines.get(key)
-    if eng is None:
-        dev = meshes._verts[0].device
-        D = 128 if face_memory is None else int(face_memory.shape[-1])
+    root = meshes._root if meshes._root is not None else meshes
+    emap = meshes._map if meshes._map is not None else list(range(len(meshes)))
+    dev = root._verts[0].device
+    D = None if face_memory is None else int(face_memory.shape[-1])
+    key = (int(rs.image_size), float(rasterizer.cameras.fov), bool(getattr(rs, 'perspective_correct', False)), D)
+    # rows of the (possibly tiled) face memory that belong to each root mesh: those of its first replica
+    starts, first, acc = {}, {}, 0
+    for j, m in enumerate(emap):
+        if m not in first:
+            first[m], starts[m] = j, acc
+        acc += int(meshes._faces[j].shape[0])
+    sig = None if face_memory is None else (face_memory.data_ptr(), face_memory._version, tuple(face_memory.shape),
+                                            tuple(sorted(starts.items())))
+    ent = root._engines.get(key)
+    if ent is None:
         S = key[0]
-        eng = PoseEngine(S, (S, S), D, fov=key[1], perspective_correct=key[2], device=dev, crop_origin=(0, 0))
-        start = 0
-        for v, f in zip(meshes._verts, meshes._faces):
+        eng = PoseEngine(S, (S, S), 128 if D is None else D, fov=key[1], perspective_correct=key[2], device=dev,
+                         crop_origin=(0, 0))
+        for v, f in zip(root._verts, root._faces):
             F_ = int(f.shape[0])
             if face_memory is None:
-                eng.register_mesh(v, f, torch.zeros((v.shape[0], D), device=dev))
+                eng.register_mesh(v, f, torch.zeros((v.shape[0], 128), device=dev))
             else:  # corner c of face f reads row 3 f + c of the flattened face memory
                 corner = torch.arange(3 * F_, device=dev, dtype=torch.int32).view(F_, 3)
-                bank = face_memory[start:start + F_].reshape(3 * F_, D).to(dev, torch.float32).contiguous()
                 vv = v.to(dev)[f.long().to(dev)].reshape(3 * F_, 3).contiguous()
-                eng.register_mesh(vv, corner, bank)
-            start += F_
-        meshes._engines[key] = eng
-    return eng
+                eng.register_mesh(vv, corner, torch.zeros((3 * F_, D), device=dev))
+        ent = root._engines[key] = {'eng': eng, 'sig': None}
+    if face_memory is not None and ent['sig'] != sig:
+        for m, (_, _, bank) in enumerate(ent['eng']._keep):
+            if m in starts:
+                F_ = bank.shape[0] // 3
+                bank.copy_(face_memory[starts[m]:starts[m] + F_].reshape(3 * F_, D).to(dev, torch.float32))
+        ent['sig'] = sig
+    return ent['eng'], torch.as_tensor(emap, dtype=torch.int32, device=dev)
 
 
 def rasterize(R, T, meshes, rasterizer, blur_radius=0):
@@ -367,13 +390,13 @@ def rasterize(R, T, meshes, rasterizer, blur_radius=0):
     of `meshes` (extend(n) for n cameras on one mesh), packed face ids."""
     if blur_radius > 0:
         raise NotImplementedError('blur_radius > 0 (soft rasterization) is not on the solver path')
-    eng = _engine_for(meshes, rasterizer)
+    eng, mesh_idx = _engine_for(meshes, rasterizer)
     n = R.shape[0]
     if n != len(meshes):
         raise ValueError('%d cameras for %d meshes (use meshes.extend(n))' % (n, len(meshes)))
-    mesh_idx = torch.arange(n, dtype=torch.int32, device=R.device)
     p2f, bary, zb = eng.rasterize(R.detach().contiguous(), T.detach().contiguous(), mesh_idx, want_zbuf=True)
-    packed = _pack_face_ids(p2f, [int(f.shape[0]) for f in meshes._faces], mesh_idx)
+    elem = torch.arange(n, dtype=torch.int32, device=R.device)   # packed ids count the faces of every batch element
+    packed = _pack_face_ids(p2f, [int(f.shape[0]) for f in meshes._faces], elem)
     return Fragments(pix_to_face=packed[..., None], zbuf=zb[..., None], bary_coords=bary[:, :, :, None, :])
 
 
@@ -381,11 +404,10 @@ def forward_interpolate(R, T, meshes, face_memory, rasterizer, blur_radius=0, mo
     """lib/MeshUtils.py:122-133 -> [n, D, S, S]; differentiable in (R, T) for mode='bilinear'."""
     if blur_radius > 0:
         raise NotImplementedError('blur_radius > 0 (soft rasterization) is not on the solver path')
-    eng = _engine_for(meshes, rasterizer, face_memory)
+    eng, mesh_idx = _engine_for(meshes, rasterizer, face_memory)
     n = R.shape[0]
     if n != len(meshes):
         raise ValueError('%d cameras for %d meshes (use meshes.extend(n))' % (n, len(meshes)))
-    mesh_idx = torch.arange(n, dtype=torch.int32, device=R.device)
     if mode == 'nearest':
         with torch.no_grad():
             p2f, bary = eng.rasterize(R.detach().contiguous(), T.detach().contiguous(), mesh_idx)

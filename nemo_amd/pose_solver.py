@@ -83,6 +83,8 @@ class SolverConfig:
     turn_off_clutter: bool = False
     perspective_correct: bool = False
     k_eps: float = 1e-8
+    # code/MeshPoseSolveAll.py:14,209-212: False = no stored grid renders (get_init_pos renders every (image, pose))
+    pre_render: bool = True
     # 6-DoF variant (code/PredUnlabeledDataset.py:283-347): Adam also moves the 2-D translation; the grid
     # samples three distances and theta = 0
     six_dof: bool = False
@@ -109,6 +111,7 @@ class SolveResult:
     init_index: torch.Tensor
     trace: Optional[torch.Tensor] = None
     trans_2d: Optional[torch.Tensor] = None   # [N,2], 6-DoF variant only
+    status: Optional[torch.Tensor] = None     # int32 [N] from the library: 1 = finite final pose, 0 = not
 
     def preds6(self) -> torch.Tensor:
         """[N,6] rows of final_pred.npz (code/PredUnlabeledDataset.py:344-347, README.md:96):
@@ -118,7 +121,8 @@ class SolveResult:
 
     def packed(self) -> torch.Tensor:
         """[N, 8] f32 record gathered across ranks: dist, elev, azim, theta, loss, init, status, pad."""
-        ok = torch.isfinite(self.campos).all(dim=1) & torch.isfinite(self.theta)
+        # the library's per-job flag (nemo_solve's d_status); results built by hand may lack it
+        ok = self.status != 0 if self.status is not None else torch.isfinite(self.campos).all(dim=1) & torch.isfinite(self.theta)
         return torch.stack([self.distance, self.elevation, self.azimuth, self.theta, self.loss,
                             self.init_index.to(torch.float32), ok.to(torch.float32),
                             torch.zeros_like(self.loss)], dim=1).contiguous()
@@ -160,6 +164,8 @@ class BatchPoseSolver:
         """get_pre_render_samples (code/MeshPoseSolveAll.py:62-82), once per set of meshes: every mesh's
         coverage under each of its grid poses.  A no-op when the store is current; the store bakes in the bank
         and grid CONTENTS, so after changing those tensors in place pass force=True."""
+        if not self.cfg.pre_render:
+            return
         key = (self.grid_C.data_ptr(), self.grid_theta.data_ptr(), len(self._grids_C))
         if force or getattr(self, '_pre_key', None) != key:
             self.engine.grid_prerender(self.grid_C, self.grid_theta, [(m, m) for m in range(len(self._grids_C))])
@@ -202,15 +208,18 @@ class BatchPoseSolver:
         self.prerender()
         C0, th0, best, _ = eng.grid_search(feats, clu, self.grid_C, self.grid_theta, n_jobs=n_jobs,
                                            img_idx=img_idx, mesh_idx=mesh_idx, grid_idx=mesh_idx)
+        status = torch.empty((n_jobs,), dtype=torch.int32, device=self.device)
         if self.cfg.six_dof:
-            out = eng.solve6(feats, clu, C0, th0, None, img_idx=img_idx, mesh_idx=mesh_idx, want_trace=want_trace)
+            out = eng.solve6(feats, clu, C0, th0, None, img_idx=img_idx, mesh_idx=mesh_idx, want_trace=want_trace,
+                             status=status)
         else:
-            out = eng.solve(feats, clu, C0, th0, img_idx=img_idx, mesh_idx=mesh_idx, want_trace=want_trace)
+            out = eng.solve(feats, clu, C0, th0, img_idx=img_idx, mesh_idx=mesh_idx, want_trace=want_trace,
+                            status=status)
         pose, loss = out[0], out[1]
         campos = pose[:, :3]
         dist, elev, azim = camera_position_to_spherical_angle(campos)
         return SolveResult(pose[:, 3], dist, elev, azim, loss, campos, best, out[2] if want_trace else None,
-                           pose[:, 4:6].contiguous() if self.cfg.six_dof else None)
+                           pose[:, 4:6].contiguous() if self.cfg.six_dof else None, status)
 
 
 def features_to_pixel_major(predicted_map: torch.Tensor) -> torch.Tensor:

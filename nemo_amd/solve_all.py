@@ -26,11 +26,16 @@ from .mesh_utils import load_off
 from .pose_solver import BatchPoseSolver, SolverConfig
 
 
+def _flag(s):
+    """The reference declares its switches `type=bool` (any non-empty string is True); here the text is read."""
+    return str(s).strip().lower() in ('1', 'true', 'yes', 'y', 'on')
+
+
 def build_parser():
     p = argparse.ArgumentParser(description='NeMo pose estimation (MI355X batched path)')
     p.add_argument('--type_', default='car', type=str)
     p.add_argument('--mesh_d', default='build', type=str)
-    p.add_argument('--turn_off_clutter', default=False, type=lambda s: str(s).lower() in ('1', 'true', 'yes'))
+    p.add_argument('--turn_off_clutter', default=False, type=_flag)
     p.add_argument('--data_pendix', default='', type=str)
     p.add_argument('--feature_path', default='saved_features', type=str)
     p.add_argument('--feature_name', default='3D512_points1saved_model_%s_799.pth', type=str)
@@ -50,6 +55,20 @@ def build_parser():
                    help='with --save_final_pred: solve every image again instead of keeping the entries the file already holds')
     p.add_argument('--accuracy_table', default='', type=str, help='directory of per-category records: print CalAccuracy table')
     p.add_argument('--batch', default=256, type=int, help='images per solve launch; the next batch is read and uploaded meanwhile')
+    p.add_argument('--streams', default=2, type=int,
+                   help='solver contexts, each on a stream of its own, taking the batches in turn: the next batch starts on the '
+                        'compute units the previous one leaves, instead of behind its slowest job')
+    # flags of code/MeshPoseSolveAll.py:12-14,20 kept so that its command lines run unchanged
+    p.add_argument('--pre_render', default=True, type=_flag,
+                   help=':14,209-212 -- False: no stored grid renders, every (image, grid pose) is rendered on the fly (get_init_pos)')
+    p.add_argument('--objectnet', default=False, type=_flag, help=':12 -- parsed and never read by the reference; accepted, ignored')
+    p.add_argument('--record_pendix', default='', type=str, help=':13 -- parsed and never read by the reference; accepted, ignored')
+    p.add_argument('--mesh_path_ref', default='../PASCAL3D/PASCAL3D+_release1.1/CAD/%s/', type=str,
+                   help=':20,131,176 -- the reference only counts its entries (one error list per CAD model); here the count '
+                        'bounds the cad_index of the annotations when the directory exists')
+    p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                   help='process group under torch.distributed.run: nccl = RCCL, one GPU per rank; gloo = rehearsal on fewer GPUs')
+    p.add_argument('--share_gpu', action='store_true', help='rehearsal only (needs --backend gloo): every rank uses GPU 0')
     return p
 
 
@@ -82,7 +101,8 @@ def build_solver(args, rec, subtypes, device):
     image_size = tuple(int(v) for v in args.image_size.split(',')) if args.image_size else syn.IMAGE_SIZES[cate]
     mesh_dir = args.mesh_path % (args.mesh_d, cate) if args.mesh_path.count('%s') == 2 else args.mesh_path
     kw = dict(image_size=image_size, feat_dim=args.feat_dim, total_epochs=args.total_epochs, lr=args.lr,
-              adam_beta_0=args.adam_beta_0, adam_beta_1=args.adam_beta_1, turn_off_clutter=args.turn_off_clutter)
+              adam_beta_0=args.adam_beta_0, adam_beta_1=args.adam_beta_1, turn_off_clutter=args.turn_off_clutter,
+              pre_render=bool(getattr(args, 'pre_render', True)))
     cfg = SolverConfig.unlabeled_6dof(**kw) if args.six_dof else SolverConfig(**kw)
     solver = BatchPoseSolver(cfg, device)
     clutter = []
@@ -94,19 +114,34 @@ def build_solver(args, rec, subtypes, device):
     return solver, clutter
 
 
+def batch_plan(n, batch):
+    """[(lo, hi)] of the launches: two quarter batches and a half batch first, so that the compute units have work a
+    quarter batch after the first byte is read instead of a whole one, then full batches."""
+    B = max(1, int(batch))
+    sizes, lo, plan = [max(1, B // 4), max(1, B // 4), max(1, B // 2)], 0, []
+    while lo < n:
+        step = sizes.pop(0) if sizes else B
+        plan.append((lo, min(n, lo + step)))
+        lo = plan[-1][1]
+    return plan
+
+
 def solve_shard(args, rec, subtypes, names, mesh_of, device, stats=None):
     """Clutter score (per subtype) -> grid init -> fused solve for the listed images: [len(names), 10] records.
 
-    The images go through in batches of --batch: while batch k is solved, a helper thread reads batch k + 1 from
-    the record into pinned memory and uploads it on a side stream (records.upload_pixel_major; DMA copies only, the
-    one transpose kernel of a batch runs when the solve before it has left the CUs), so the file path costs
-    max(read + upload, solve) per batch instead of their sum; the first batch comes in under mesh registration and
-    the grid pre-render.  Batches do not change results (every job is independent)."""
+    The images go through in batches (batch_plan): while earlier batches are solved, a helper thread reads the next one
+    from the record into pinned memory and uploads it on a side stream (records.upload_pixel_major; DMA copies only,
+    the one transpose kernel of a batch runs when compute units are free).  Batches alternate between --streams solver
+    contexts, each with its own stream and workspaces: a solve is one workgroup per job for all its steps, so a launch
+    ends with its slowest job while most compute units idle; the next batch's launches, queued on the other stream,
+    take those units as they come free.  Batches do not change results (every job is independent)."""
     from concurrent.futures import ThreadPoolExecutor
     dev = torch.device(device)
     if dev.index is None:
         dev = torch.device('cuda', torch.cuda.current_device())
-    n, B = len(names), max(1, int(getattr(args, 'batch', 256) or 256))
+    n = len(names)
+    plan = batch_plan(n, getattr(args, 'batch', 256) or 256)
+    n_ctx = max(1, min(int(getattr(args, 'streams', 2) or 1), len(plan)))
     side = torch.cuda.Stream(dev)
 
     def load(lo, hi):
@@ -118,27 +153,39 @@ def solve_shard(args, rec, subtypes, names, mesh_of, device, stats=None):
         return feats, ready
 
     out, clus, inits = [], [], []
+    main = torch.cuda.current_stream(dev)
     with ThreadPoolExecutor(max_workers=1) as helper:
-        nxt = helper.submit(load, 0, min(B, n))  # the first batch comes in while the meshes are registered and pre-rendered
-        solver, clutter = build_solver(args, rec, subtypes, dev)
-        solver.engine.reserve(min(B, n), int(solver.grid_theta.shape[1]))
-        solver.prerender()
-        for lo in range(0, n, B):
-            hi = min(lo + B, n)
+        nxt = helper.submit(load, *plan[0])  # the first batch comes in while the meshes are registered and pre-rendered
+        biggest = max(hi - lo for lo, hi in plan)
+        ctxs = []
+        for _ in range(n_ctx):
+            solver, clutter = build_solver(args, rec, subtypes, dev)
+            solver.engine.reserve(biggest, int(solver.grid_theta.shape[1]))
+            solver.prerender()
+            ctxs.append((solver, clutter, torch.cuda.Stream(dev) if n_ctx > 1 else main))
+        for st in ctxs:
+            st[2].wait_stream(main)      # set-up (registration, pre-render) ran on the current stream
+        for bi, (lo, hi) in enumerate(plan):
             feats, ready = nxt.result()
-            if hi < n:
-                nxt = helper.submit(load, hi, min(hi + B, n))
-            main = torch.cuda.current_stream(dev)
-            main.wait_event(ready)
-            feats.record_stream(main)
-            clu = None if solver.cfg.turn_off_clutter else solver.clutter_scores_by_group(feats, mesh_of[lo:hi], clutter)
-            mesh_idx = torch.tensor(mesh_of[lo:hi], dtype=torch.int32, device=dev)
-            res = solver.solve_all(feats, None, mesh_idx, clutter_scores=clu)
-            t2 = res.trans_2d if res.trans_2d is not None else torch.zeros((hi - lo, 2), device=dev)
-            out.append(torch.cat([res.packed(), t2], dim=1))
-            clus.append(clu)
-            inits.append(res.init_index)
-    info = dict(solver=solver, init_index=torch.cat(inits), clu=None if clus[0] is None else torch.cat(clus))
+            if bi + 1 < len(plan):
+                nxt = helper.submit(load, *plan[bi + 1])
+            solver, clutter, stream = ctxs[bi % n_ctx]
+            with torch.cuda.stream(stream):
+                stream.wait_event(ready)
+                feats.record_stream(stream)
+                clu = None if solver.cfg.turn_off_clutter else solver.clutter_scores_by_group(feats, mesh_of[lo:hi], clutter)
+                mesh_idx = torch.tensor(mesh_of[lo:hi], dtype=torch.int32, device=dev)
+                res = solver.solve_all(feats, None, mesh_idx, clutter_scores=clu)
+                t2 = res.trans_2d if res.trans_2d is not None else torch.zeros((hi - lo, 2), device=dev)
+                out.append(torch.cat([res.packed(), t2], dim=1))
+                clus.append(clu)
+                inits.append(res.init_index)
+                del feats
+        for st in ctxs:
+            main.wait_stream(st[2])
+    for t in out + inits + [c for c in clus if c is not None]:
+        t.record_stream(main)
+    info = dict(solver=ctxs[0][0], init_index=torch.cat(inits), clu=None if clus[0] is None else torch.cat(clus))
     return torch.cat(out), info
 
 
@@ -200,25 +247,56 @@ def main(argv=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.share_gpu:
+        if world > 1 and args.backend != 'gloo':
+            print('solve_all: --share_gpu needs --backend gloo (RCCL refuses two ranks on one GPU)', file=sys.stderr)
+            return 2
+        local = 0
+    if not torch.cuda.is_available():
+        print('solve_all (rank %d): no GPU visible; the pose-solve path has no CPU fallback' % rank, file=sys.stderr)
+        return 3
+    torch.cuda.set_device(local)             # before any collective: RCCL binds the communicator to the current device
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl' if torch.cuda.is_available() else 'gloo')
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group('gloo')
     done = {}
     if args.save_final_pred and not args.no_reload and os.path.exists(args.save_final_pred):  # PredUnlabeledDataset.py:297-303
         done = load_final_pred(args.save_final_pred)
     names, _, recs = solve_category(args, 'cuda:%d' % local, skip=set(done))
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
     if rank != 0:
         return 0
     anno_dir = args.anno_path % args.type_ if '%s' in args.anno_path else args.anno_path
     if args.save_final_pred:                                                       # PredUnlabeledDataset.py:344-352
         os.makedirs(os.path.dirname(os.path.abspath(args.save_final_pred)), exist_ok=True)
-        preds = recs[:, [0, 3, 1, 2, 8, 9]]                                        # distance, theta, elevation, azimuth, t0, t1
-        done.update({n: preds[i] for i, n in enumerate(names)})
+        preds = recs[:, [0, 3, 1, 2, 8, 9]].astype(np.float64)                     # distance, theta, elevation, azimuth, t0, t1
+        if done:
+            # resumed run: the accuracy below is the CATEGORY's, so the entries kept from the file are scored as
+            # well -- their rows rebuilt from the stored predictions (loss / init are not in the file: NaN / 0)
+            kept = [k for k in done if k not in set(names)]
+            rows = np.zeros((len(kept), RECORD_WIDTH), dtype=np.float64)
+            for i, k in enumerate(kept):
+                d = np.asarray(done[k], dtype=np.float64).reshape(-1)
+                rows[i, [0, 3, 1, 2]] = d[:4]
+                rows[i, 4], rows[i, 6] = np.nan, float(np.all(np.isfinite(d[:4])))
+                rows[i, 8:10] = d[4:6] if d.size >= 6 else 0.0
+            names, recs = kept + list(names), np.concatenate([rows, recs.astype(np.float64)], 0)
+        done.update({n: preds[i] for i, n in enumerate(names[len(names) - len(preds):])})
         np.savez(args.save_final_pred, **done)
+    n_cad = None
+    ref_dir = args.mesh_path_ref % args.type_ if '%s' in args.mesh_path_ref else args.mesh_path_ref
+    if ref_dir and os.path.isdir(ref_dir):
+        n_cad = len(os.listdir(ref_dir))                                           # :176: one error list per CAD model
     total_error, cads = errors_from_records(names, recs, anno_dir)
+    if n_cad is not None and any(c < 1 or c > n_cad for c in cads):
+        print('solve_all: an annotation names a cad_index outside 1..%d (%s)' % (n_cad, ref_dir), file=sys.stderr)
+        return 4
     if args.save_accuracy:                                                         # :273-274
         records.save_category_errors(args.save_accuracy, total_error, cads)
     elif total_error:                                                              # :275-287

@@ -66,11 +66,15 @@ def test_campos_to_R_T_bit_exact(oracle):
             assert np.array_equal(R[i], Ro) and np.array_equal(T[i], To)
 
 
+K_EPS = [1e-8, 1e-30]  # PyTorch3D's kEpsilon: 1e-8 in current sources, 1e-30 in the 0.2.0 era
+
+
+@pytest.mark.parametrize('k_eps', K_EPS)
 @pytest.mark.parametrize('persp', [False, True])
 @pytest.mark.parametrize('cate,hw,nv', [('car', (256, 384), 300), ('bottle', (384, 256), 200),
                                         ('aeroplane', (640, 800), 1000)])
-def test_rasterize_bit_exact(oracle, cate, hw, nv, persp):
-    sc = make_scene(cate, hw, nv, n_img=1, perspective_correct=persp)
+def test_rasterize_bit_exact(oracle, cate, hw, nv, persp, k_eps):
+    sc = make_scene(cate, hw, nv, n_img=1, perspective_correct=persp, k_eps=k_eps)
     eng = _engine(sc)
     rng = np.random.default_rng(2)
     n = 12
@@ -106,8 +110,9 @@ def test_rasterize_offscreen_and_degenerate(oracle):
     assert (p2f[0] >= 0).sum() == 0  # shifted out of the window
 
 
+@pytest.mark.parametrize('k_eps', K_EPS)
 @pytest.mark.parametrize('persp', [False, True])
-def test_rasterize_triangle_soup_fuzz(oracle, persp):
+def test_rasterize_triangle_soup_fuzz(oracle, persp, k_eps):
     """Nothing cuboid-specific in the rasteriser: random triangle soups with duplicated faces (ties: the lowest face
     index must win), interpenetrating and sliver triangles, degenerate faces (repeated vertex, collinear), faces
     larger than the whole view (the non-masked list path) and vertices behind the camera.  pix_to_face, barycentrics
@@ -115,7 +120,7 @@ def test_rasterize_triangle_soup_fuzz(oracle, persp):
     from nemo_amd.engine import PoseEngine
     S, h, w, D = 48, 32, 48, 128
     s = syn.ndc_scale(12.0)
-    cfg = oracle.make_cfg(S, h, w, D, s, perspective_correct=persp)
+    cfg = oracle.make_cfg(S, h, w, D, s, perspective_correct=persp, k_eps=k_eps)
     for seed in range(6):
         rng = np.random.default_rng(100 + seed)
         V = 120
@@ -130,7 +135,7 @@ def test_rasterize_triangle_soup_fuzz(oracle, persp):
         verts[104:107] = verts[10] + np.outer(np.arange(3), [0.1, 0.05, 0.0]).astype(np.float32)
         faces[73] = (104, 105, 106)                                  # collinear
         bank = syn.unit_rows(rng, V, D)
-        eng = PoseEngine(S, (h, w), D, perspective_correct=persp)
+        eng = PoseEngine(S, (h, w), D, perspective_correct=persp, k_eps=k_eps)
         eng.register_mesh(verts, faces, bank)
         n = 6
         C, th = random_poses(rng, n, 5.0, spread=0.3)
@@ -571,7 +576,7 @@ def test_hot_calls_do_not_allocate():
     idx, mesh, C0x, th0x, pose, loss, losses = oversized(C0, th0)
     n = idx.shape[0]
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-    rc = eng.lib.nemo_solve(eng.ctx, n, p(idx), p(mesh), p(wl.feats), p(clu), p(C0x), p(th0x), p(pose), p(loss), None, eng._stream())
+    rc = eng.lib.nemo_solve(eng.ctx, n, p(idx), p(mesh), p(wl.feats), p(clu), p(C0x), p(th0x), p(pose), p(loss), None, None, eng._stream())
     assert rc == -3 and b'nemo_workspace_reserve' in eng.lib.nemo_last_error(eng.ctx)
     rc = eng.lib.nemo_grid_search(eng.ctx, n, p(idx), p(mesh), p(mesh), p(wl.feats), p(clu), p(s.grid_C), p(s.grid_theta), 144,
                                   p(losses), p(pose), p(loss), None, eng._stream())
@@ -580,28 +585,49 @@ def test_hot_calls_do_not_allocate():
 
 def test_non_finite_job_is_flagged_not_fatal():
     """A job whose start pose is not finite (the reference scores such solves as pi/2, code/MeshPoseSolveAll.py:262-263)
-    comes back non-finite with status 0 in the gathered record; the launch completes and the other jobs of the batch
-    are bit-identical to the same jobs solved without it."""
+    comes back non-finite with status 0 -- from the C ABI's d_status (nemo_solve, nemo_solve6, nemo_solve_static) and,
+    through it, in the gathered record; the launch completes and the other jobs of the batch are bit-identical to the
+    same jobs solved without it."""
     from nemo_amd.pose_solver import SolverConfig
     from nemo_amd.workloads import twelve_class_workload
     wl = twelve_class_workload(6, seed=21, cfg=SolverConfig(total_epochs=40))
     s, eng = wl.solver, wl.solver.engine
     clu = eng.clutter_score(wl.feats, wl.clutter)
     C0, th0, _, _ = eng.grid_search(wl.feats, clu, s.grid_C, s.grid_theta, mesh_idx=wl.mesh_idx, grid_idx=wl.mesh_idx)
-    good_pose, good_loss = eng.solve(wl.feats, clu, C0, th0, mesh_idx=wl.mesh_idx)[:2]
+    st_good = torch.full((6,), -7, dtype=torch.int32, device='cuda')
+    good_pose, good_loss = eng.solve(wl.feats, clu, C0, th0, mesh_idx=wl.mesh_idx, status=st_good)[:2]
+    assert st_good.tolist() == [1] * 6
     bad_C, bad_th = C0.clone(), th0.clone()
     bad_C[2, 1] = float('nan')
     bad_th[4] = float('inf')
-    pose, loss = eng.solve(wl.feats, clu, bad_C, bad_th, mesh_idx=wl.mesh_idx)[:2]
+    want = [1, 1, 0, 1, 0, 1]
+    st = torch.full((6,), -7, dtype=torch.int32, device='cuda')
+    pose, loss = eng.solve(wl.feats, clu, bad_C, bad_th, mesh_idx=wl.mesh_idx, status=st)[:2]
     torch.cuda.synchronize()
     keep = torch.tensor([0, 1, 3, 5], device='cuda')
     assert torch.equal(pose[keep], good_pose[keep]) and torch.equal(loss[keep], good_loss[keep])
     assert not torch.isfinite(pose[2]).all() and not torch.isfinite(pose[4]).all()
+    assert st.tolist() == want
+    for kw in ({'static': True}, {}):                                   # the other two entry points write the same flags
+        st2 = torch.full((6,), -7, dtype=torch.int32, device='cuda')
+        if kw:
+            eng.solve(wl.feats, clu, bad_C, bad_th, mesh_idx=wl.mesh_idx, status=st2, **kw)
+        else:
+            tr = torch.zeros(6, 2, device='cuda')
+            tr[1, 0] = float('nan')                                     # trans_2d counts too
+            eng.solve6(wl.feats, clu, bad_C, bad_th, tr, mesh_idx=wl.mesh_idx, status=st2)
+        assert st2.tolist() == (want if kw else [1, 0, 0, 1, 0, 1])
     from nemo_amd.pose_solver import SolveResult
     from nemo_amd.mesh_utils import camera_position_to_spherical_angle
     d, e, a = camera_position_to_spherical_angle(pose[:, :3])
-    rec = SolveResult(pose[:, 3], d, e, a, loss, pose[:, :3], torch.zeros(6, dtype=torch.int32, device='cuda')).packed().cpu().numpy()
-    assert rec[:, 6].tolist() == [1.0, 1.0, 0.0, 1.0, 0.0, 1.0]
+    init = torch.zeros(6, dtype=torch.int32, device='cuda')
+    rec = SolveResult(pose[:, 3], d, e, a, loss, pose[:, :3], init, status=st).packed().cpu().numpy()
+    assert rec[:, 6].tolist() == [float(v) for v in want]
+    rec = SolveResult(pose[:, 3], d, e, a, loss, pose[:, :3], init).packed().cpu().numpy()   # hand-built result: derived flag
+    assert rec[:, 6].tolist() == [float(v) for v in want]
+    # the batched driver carries the library's flag into its records
+    res = s.solve_all(wl.feats, wl.clutter, wl.mesh_idx)
+    assert res.status is not None and res.status.tolist() == [1] * 6 and res.packed()[:, 6].tolist() == [1.0] * 6
 
 
 def test_against_committed_fixture():
@@ -1057,6 +1083,16 @@ def test_module_batched_modes(oracle):
     fr2 = mu.rasterize(R, T, meshes.extend(3), rasterizer())
     assert torch.equal(crop(fr2.pix_to_face[..., 0]), fr.pix_to_face[..., 0])
     assert torch.equal(crop(fr2.bary_coords[..., 0, :].permute(0, 3, 1, 2)), fr.bary_coords[..., 0, :].permute(0, 3, 1, 2))
+    # every extend(n) replica is served by the engine of the Meshes it came from, and a face memory that changes
+    # (updated in place, or another tensor) refreshes the registered bank instead of building a new context
+    fm3 = fm.repeat(3, 1, 1).view(-1, *fm.shape[1:]).contiguous()
+    for _ in range(3):
+        fm3.mul_(0.5)
+        again = mu.forward_interpolate(R, T, meshes.extend(3), fm3, rasterizer())
+    assert torch.equal(again, full * 0.125)                           # powers of two: exact
+    other = mu.forward_interpolate(R, T, meshes.extend(3), (fm3 * 8.0).contiguous(), rasterizer())
+    assert torch.equal(other, full)
+    assert len(meshes._engines) == 2 and all(len(e['eng']._keep) == 1 for e in meshes._engines.values())
     # off_set_mesh / deform_verts (:212-213), forward only: offsets of zero change nothing, a rigid shift equals
     # a module built from the shifted vertices
     off = mu.MeshInterpolateModule(pascal(a), torch.as_tensor(a.faces), torch.as_tensor(a.bank), rasterizer(), post_process=crop,
@@ -1121,6 +1157,14 @@ def test_solve_all_runner_from_files(tmp_path, oracle):
     with records.FeatureRecord(rec_path) as rec:
         recs_b, _ = solve_all.solve_shard(args, rec, ['mesh01', 'mesh02'], all_names, mesh_of, 'cuda:0')
     assert torch.equal(recs_b, recs)
+    args.streams = 1                                            # one context, batches strictly one after the other
+    with records.FeatureRecord(rec_path) as rec:
+        recs_s, _ = solve_all.solve_shard(args, rec, ['mesh01', 'mesh02'], all_names, mesh_of, 'cuda:0')
+    assert torch.equal(recs_s, recs)
+    args.pre_render = False                                     # :14,209-212: every (image, grid pose) rendered on the fly
+    with records.FeatureRecord(rec_path) as rec:
+        recs_f, info_f = solve_all.solve_shard(args, rec, ['mesh01', 'mesh02'], all_names, mesh_of, 'cuda:0')
+    assert torch.equal(info_f['init_index'], info['init_index']) and torch.equal(recs_f, recs)
     gC, gth = syn.pose_grid(scs[0].distance)
     for i, k in enumerate(mesh_of):
         sc = scs[k]
@@ -1152,6 +1196,54 @@ def test_solve_all_runner_from_files(tmp_path, oracle):
         assert sorted(z.files) == sorted(feats)
         assert np.array_equal(z[keep], np.full(6, 7.0))                 # untouched
         assert np.array_equal(z[gone].astype(np.float32), first[gone].astype(np.float32))   # solved again: same result
+        assert all(z[n].dtype == np.float64 for n in z.files)           # reloaded and new entries alike
+    # a resumed run scores the WHOLE category: the entries kept from the file count too (here one of them was
+    # overwritten with a far-off pose, so the record has five errors and that one is large)
+    np.savez(pred_path, **marked)
+    acc2 = str(tmp_path / 'acc' / 'car_resumed.npz')
+    assert solve_all.main(['--type_', 'car', '--record_file', rec_path, '--mesh_path', str(mesh_dir), '--anno_path', str(anno_dir),
+                           '--image_size', '256,384', '--six_dof', '--save_final_pred', pred_path, '--save_accuracy', acc2,
+                           '--mesh_path_ref', str(mesh_dir), '--objectnet', 'False', '--record_pendix', 'x']) == 0
+    te2 = records.load_category_errors(acc2)
+    kept_order = [k for k in first if k in marked]                      # the kept entries come first, in file order
+    assert te2.shape == (5,) and np.all(np.isfinite(te2)) and te2[kept_order.index(keep)] > 0.3
+
+
+def test_solve_all_runner_two_ranks_share_one_gpu(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 -m nemo_amd.solve_all` (the N-rank entry that replaces
+    InferenceNeMo.sh:42-50,67-81), rehearsed on the one GPU of this box with --backend gloo --share_gpu: each rank binds
+    its device before the process group exists, solves its contiguous shard and the records come back through the one
+    gather -- the file rank 0 writes is identical, entry for entry, to the single-process run's."""
+    import socket
+    import subprocess
+    import sys
+    from nemo_amd import mesh_utils as mu, records
+    sc = make_scene(image_hw=(256, 384), n_img=5, seed=23)
+    mesh_dir = tmp_path / 'CAD_build' / 'car'
+    os.makedirs(mesh_dir)
+    mu.save_off(str(mesh_dir / '01.off'), np.stack([sc.verts[:, 0], -sc.verts[:, 2], sc.verts[:, 1]], 1), sc.faces)
+    names = ['img_%d' % i for i in range(5)]
+    rec_path = str(tmp_path / 'rec.npz')
+    records.write_feature_record(rec_path, {'mesh01': sc.bank}, {'mesh01': syn.unit_rows(np.random.default_rng(5), 4, sc.D)},
+                                 {'mesh01': names}, {n: np.ascontiguousarray(sc.feats[i].transpose(2, 0, 1)) for i, n in enumerate(names)})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ['--type_', 'car', '--record_file', rec_path, '--mesh_path', str(mesh_dir), '--anno_path', '', '--image_size', '256,384',
+              '--total_epochs', '60']
+    one, two = str(tmp_path / 'one.npz'), str(tmp_path / 'two.npz')
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    r1 = subprocess.run([sys.executable, '-m', 'nemo_amd.solve_all', *common, '--save_final_pred', one], env=env, cwd=root,
+                        capture_output=True, text=True, timeout=110)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    r2 = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                         '--master-port', str(port), '-m', 'nemo_amd.solve_all', *common, '--save_final_pred', two,
+                         '--backend', 'gloo', '--share_gpu'], env=env, cwd=root, capture_output=True, text=True, timeout=110)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    with np.load(one) as a, np.load(two) as b:
+        assert sorted(a.files) == sorted(b.files) == sorted(names)
+        assert all(np.array_equal(a[n], b[n]) and np.all(np.isfinite(a[n])) for n in names)
 
 
 def test_dense_pose_grid_search(oracle):

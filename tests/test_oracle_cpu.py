@@ -78,14 +78,18 @@ def _window(sc, a):
     return np.ascontiguousarray(raster_np.crop(a, sc.cfg.S, sc.cfg.h, sc.cfg.w, sc.cfg.r0, sc.cfg.c0))
 
 
+K_EPS = [1e-8, 1e-30]  # PyTorch3D's kEpsilon: 1e-8 in current sources, 1e-30 in the 0.2.0 era
+
+
+@pytest.mark.parametrize('k_eps', K_EPS)
 @pytest.mark.parametrize('persp', [False, True])
 @pytest.mark.parametrize('cate,hw,nv', [('car', (256, 384), 300), ('bottle', (384, 256), 200), ('aeroplane', (640, 800), 1000)])
-def test_two_independent_rasterizers_agree(oracle, cate, hw, nv, persp):
+def test_two_independent_rasterizers_agree(oracle, cate, hw, nv, persp, k_eps):
     """The discrete half of the path has two lineages: the C oracle's per-pixel loop and oracle/raster_np.py
     (float32 array operations over all pixels x all faces, written from SURVEY 8a row P4, sharing no code with the
     C file).  pix_to_face, barycentrics and z of the full S x S image agree bit for bit, and so does the crop."""
     from oracle import raster_np
-    sc = make_scene(cate, hw, nv, n_img=1, perspective_correct=persp)
+    sc = make_scene(cate, hw, nv, n_img=1, perspective_correct=persp, k_eps=k_eps)
     rng = np.random.default_rng(12)
     C, th = random_poses(rng, 4, sc.distance, spread=0.3)
     for i in range(4):
@@ -99,15 +103,16 @@ def test_two_independent_rasterizers_agree(oracle, cate, hw, nv, persp):
         assert np.array_equal(pw, _window(sc, p2)) and np.array_equal(bw, _window(sc, b2))
 
 
+@pytest.mark.parametrize('k_eps', K_EPS)
 @pytest.mark.parametrize('persp', [False, True])
-def test_two_independent_rasterizers_agree_on_triangle_soups(oracle, persp):
+def test_two_independent_rasterizers_agree_on_triangle_soups(oracle, persp, k_eps):
     """Same, on the inputs that exercise the decision rules: duplicated faces (ties -> lowest index), repeated
     vertices and collinear faces (kEps skip), a triangle larger than the view in both windings, interpenetrating
     slivers, vertices behind the camera (pz < 0)."""
     from oracle import raster_np
     S, h, w, D = 48, 32, 48, 128
     s = syn.ndc_scale(12.0)
-    cfg = oracle.make_cfg(S, h, w, D, s, perspective_correct=persp)
+    cfg = oracle.make_cfg(S, h, w, D, s, perspective_correct=persp, k_eps=k_eps)
     ties = 0
     for seed in range(6):
         rng = np.random.default_rng(100 + seed)
@@ -266,3 +271,30 @@ def test_rasterizer_lineages_agree_on_random_soups_hypothesis(oracle):
         assert np.all(bf[~cov] == -1) and np.all(b2[~cov] == -1)
 
     check()
+
+
+def test_reference_op_sequence_baseline_matches_the_oracle(oracle):
+    """oracle/ref_sequence.py (the CPU baseline of SURVEY 8d: the reference's op sequence with torch.autograd and
+    torch.optim.Adam) computes what the C oracle computes: same rendered map, same loss, same dL/dC, dL/dtheta at a
+    pose, and its Adam steps follow the oracle's solve."""
+    import torch
+    from oracle.ref_sequence import ReferenceSequence
+    sc = make_scene(n_img=1, seed=33)
+    seq = ReferenceSequence(sc)
+    C, th = random_poses(np.random.default_rng(4), 1, sc.distance)
+    e = oracle.evaluate(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[0], sc.clus[0], C[0], th[0], want_maps=True)
+    Ct = torch.tensor(C[:1], requires_grad=True)
+    tht = torch.tensor(th[:1], requires_grad=True)
+    out = seq.render(Ct, tht)                                            # [D,h,w]
+    ref = oracle.interpolate(sc.cfg, e['pix_to_face'], e['bary'], sc.faces, sc.bank)
+    assert np.abs(out.detach().permute(1, 2, 0).numpy() - ref).max() <= 2e-6
+    loss = seq.loss_fun(torch.sum(out * seq.predicted_map, dim=0))
+    loss.backward()
+    assert abs(loss.item() - e['loss']) <= 1e-5 * abs(e['loss'])
+    g = np.r_[Ct.grad[0].numpy(), tht.grad.numpy()]
+    want = np.r_[e['gC'], e['gtheta']]
+    assert np.abs(g - want).max() <= 2e-4 * np.abs(want).max()
+    tab = syn.adam_table(4)
+    oC, oth, _, _ = oracle.solve(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[0], sc.clus[0], C[0], th[0], tab)
+    rC, rth, losses = seq.adam_steps(C[0], th[0], 4)
+    assert np.abs(rC - oC).max() <= 1e-4 and abs(rth - oth) <= 1e-4 and len(losses) == 4
