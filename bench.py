@@ -288,6 +288,11 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         print(f'bench.py: --gpus {args.gpus} but the launcher started {world} ranks', file=sys.stderr)
         sys.exit(2)
+    # The process-per-core CPU baseline runs FIRST, before this process has touched the GPU: its workers are CPU-only
+    # children, and a GPU box bounds the number of processes that may hold the device at once.
+    cpu_autograd = None
+    if world == 1 and not args.no_cpu_baseline and torch.cuda.device_count() > 0:
+        cpu_autograd = cpu_baseline_autograd(min(16, os.cpu_count() or 1))
     if not torch.cuda.is_available():
         print(f'bench.py (rank {rank}): no GPU visible; the pose-solve path has no CPU fallback', file=sys.stderr)
         sys.exit(3)
@@ -392,7 +397,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             n_sample = args.cpu_sample or 3 * min(16, os.cpu_count() or 1)
             out['cpu_baseline'] = cpu_baseline(wl, n_sample)
-            out['cpu_baseline_autograd'] = cpu_baseline_autograd(min(16, os.cpu_count() or 1))
+            out['cpu_baseline_autograd'] = cpu_autograd
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -99,6 +99,14 @@ class FeatureRecord:
         off, shape = lay
         if shape != tuple(dst.shape):
             raise ValueError('feature map %r has shape %s, expected %s' % (name, shape, tuple(dst.shape)))
+        if getattr(self, 'use_mmap', False):  # copy out of a read-only mapping of the record instead of pread
+            if not hasattr(self, '_mm'):
+                import mmap
+                self._mm_fh = open(self.path, 'rb')
+                self._mm = np.frombuffer(mmap.mmap(self._mm_fh.fileno(), 0, access=mmap.ACCESS_READ), dtype=np.uint8)
+            n = dst.size * 4
+            np.copyto(dst.reshape(-1).view(np.uint8), self._mm[off:off + n])
+            return
         own = fd is None
         if own:
             fd = os.open(self.path, os.O_RDONLY)

@@ -16,6 +16,7 @@ from __future__ import annotations
 import argparse
 import os
 import sys
+import time
 
 import numpy as np
 import torch
@@ -144,18 +145,33 @@ def solve_shard(args, rec, subtypes, names, mesh_of, device, stats=None):
     n_ctx = max(1, min(int(getattr(args, 'streams', 2) or 1), len(plan)))
     side = torch.cuda.Stream(dev)
 
+    timed = stats is not None   # optional timeline (tools/runner_timeline.py): device times of every batch's phases
+    main = torch.cuda.current_stream(dev)
+    marks = []
+    if timed:
+        t_host0 = time.perf_counter()
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record(main)
+
+    # the reader runs ahead of the launches by up to AHEAD batches (device memory: AHEAD + 2 batches of maps at most)
+    import threading
+    AHEAD = 3
+    slots = threading.Semaphore(AHEAD)
+
     def load(lo, hi):
+        slots.acquire()
         torch.cuda.set_device(dev)
         with torch.cuda.stream(side):
             feats = rec.upload_pixel_major(names[lo:hi], dev, stats=stats)
-            ready = torch.cuda.Event()
+            ready = torch.cuda.Event(enable_timing=timed)
             ready.record(side)
+        if timed:
+            marks.append(('maps %d..%d queued (host)' % (lo, hi), time.perf_counter() - t_host0, None))
         return feats, ready
 
     out, clus, inits = [], [], []
-    main = torch.cuda.current_stream(dev)
     with ThreadPoolExecutor(max_workers=1) as helper:
-        nxt = helper.submit(load, *plan[0])  # the first batch comes in while the meshes are registered and pre-rendered
+        loads = [helper.submit(load, lo, hi) for lo, hi in plan]  # read from now on, while the meshes are registered and pre-rendered
         biggest = max(hi - lo for lo, hi in plan)
         ctxs = []
         for _ in range(n_ctx):
@@ -166,13 +182,15 @@ def solve_shard(args, rec, subtypes, names, mesh_of, device, stats=None):
         for st in ctxs:
             st[2].wait_stream(main)      # set-up (registration, pre-render) ran on the current stream
         for bi, (lo, hi) in enumerate(plan):
-            feats, ready = nxt.result()
-            if bi + 1 < len(plan):
-                nxt = helper.submit(load, *plan[bi + 1])
+            feats, ready = loads[bi].result()
+            loads[bi] = None
             solver, clutter, stream = ctxs[bi % n_ctx]
             with torch.cuda.stream(stream):
                 stream.wait_event(ready)
                 feats.record_stream(stream)
+                if timed:
+                    b0 = torch.cuda.Event(enable_timing=True)
+                    b0.record(stream)
                 clu = None if solver.cfg.turn_off_clutter else solver.clutter_scores_by_group(feats, mesh_of[lo:hi], clutter)
                 mesh_idx = torch.tensor(mesh_of[lo:hi], dtype=torch.int32, device=dev)
                 res = solver.solve_all(feats, None, mesh_idx, clutter_scores=clu)
@@ -181,10 +199,19 @@ def solve_shard(args, rec, subtypes, names, mesh_of, device, stats=None):
                 clus.append(clu)
                 inits.append(res.init_index)
                 del feats
+                slots.release()
+                if timed:
+                    b1 = torch.cuda.Event(enable_timing=True)
+                    b1.record(stream)
+                    marks.append(('batch %d..%d on stream %d' % (lo, hi, bi % n_ctx), time.perf_counter() - t_host0, (ready, b0, b1)))
         for st in ctxs:
             main.wait_stream(st[2])
     for t in out + inits + [c for c in clus if c is not None]:
         t.record_stream(main)
+    if timed:
+        torch.cuda.synchronize(dev)
+        stats['timeline'] = [(label, 1e3 * th) + (tuple(ev0.elapsed_time(e) for e in evs) if evs else ())
+                             for label, th, evs in marks]
     info = dict(solver=ctxs[0][0], init_index=torch.cat(inits), clu=None if clus[0] is None else torch.cat(clus))
     return torch.cat(out), info
 

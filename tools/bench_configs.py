@@ -104,6 +104,7 @@ def dense12(n_images=1024, seed=4):
     block.  Also timed: the list path (no dense maps) the same search used to fall back to."""
     cfg = SolverConfig()
     out = {}
+    saved = {k: os.environ.get(k) for k in ('NEMO_PRERENDER_MAP_GB', 'NEMO_GRID_NO_MFMA')}
     for mode in ('tiled_matrix_core', 'list_path'):
         os.environ['NEMO_PRERENDER_MAP_GB'] = '48'
         os.environ['NEMO_GRID_NO_MFMA'] = '1' if mode == 'list_path' else '0'
@@ -138,6 +139,13 @@ def dense12(n_images=1024, seed=4):
                      'best': res[2][:8].tolist()}
         del s, eng, feats, clu
         torch.cuda.empty_cache()
+    # the switches are read at nemo_ctx_create: put them back, or the configurations that follow in this process
+    # run their grid search on the list path (round 2's "0.835 s against 0.652 s" for `big`, profiles/r03_cfg5_discrepancy.md)
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
     out['same_argmin_on_the_first_images'] = out['tiled_matrix_core']['best'] == out['list_path']['best']
     return {'config': 'dense pose grid, 12 classes (9720 poses x 12 meshes)', **out}
 
