@@ -206,6 +206,285 @@ __global__ __launch_bounds__(1024) void grid_mfma_lds_kernel(int hw, int N, int 
   }
 }
 
+// ---------------------------------------------------------------- the same contraction without materialised renders
+// A dense grid (BASELINE config 4: 9720 poses x 12 classes) would need 478 GB of rendered maps.  What a render holds
+// per (pose, pixel) is three bank rows and three weights, so nemo_grid_prerender stores exactly that -- a 20-byte
+// record: three 16-bit vertex ids + a covered flag, three barycentrics -- and the kernel below builds the pose
+// operand of the per-pixel GEMM in LDS from the records and the (L2-resident) vertex bank:
+//   row(g, p) = (b0 * bank[v0] + b1 * bank[v1]) + b2 * bank[v2]     (the arithmetic of interpolate_kernel, bit for bit)
+// Work split inside the 512-thread workgroup (128 poses x 64 jobs per pass; 8 waves so that a builder's 16 row
+// fragments fit its 256 registers):
+//   waves 0-3 stage the jobs' feature rows (HBM) and the records (HBM) one pixel ahead, as grid_mfma_lds_kernel does;
+//   waves 4-7 build the 128 pose rows of the NEXT pixel in rounds of bank-row loads (L2) placed between the operand
+//             steps of the CURRENT pixel's matrix instructions -- their vector-memory queue holds nothing but those
+//             loads, so a round never waits behind an HBM load (the counter is in order);
+//   all 8 waves multiply: wave w owns (job tile w / 4, pose tile w % 4); a tile whose 32 poses do not cover the
+//   pixel is skipped (all its products are zero and so are its loss terms).
+// pack_rec_kernel turns the rasteriser's (pix_to_face, bary) of a block of poses into the records.
+struct RecVid { uint32_t v01, v2c; };  // v0 | v1 << 16, v2 | covered << 16
+__global__ void pack_rec_kernel(size_t npix, size_t hw, int G, int g0, int gb, const MeshDesc *meshes, const int32_t *mesh_of_job,
+                                const int32_t *p2f, const float *bary, RecVid *vid, float *bout) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // (job = pair * gb + b, pixel)
+  if (k >= npix) return;
+  const size_t job = k / hw, pix = k - job * hw;
+  const size_t pair = job / gb, b = job - pair * gb;
+  const size_t dst = (pair * G + g0 + b) * hw + pix;
+  const int f = p2f[k];
+  RecVid r{0u, 0u};
+  float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+  if (f >= 0) {
+    const int32_t *fc = meshes[mesh_of_job[job]].faces + 3 * (size_t)f;
+    r.v01 = (uint32_t)fc[0] | ((uint32_t)fc[1] << 16);
+    r.v2c = (uint32_t)fc[2] | (1u << 16);
+    b0 = bary[3 * k]; b1 = bary[3 * k + 1]; b2 = bary[3 * k + 2];
+  }
+  vid[dst] = r;
+  bout[3 * dst] = b0; bout[3 * dst + 1] = b1; bout[3 * dst + 2] = b2;
+}
+
+constexpr int GR_T = 4;    // pose tiles per workgroup (128 poses)
+constexpr int GR_JT = 2;   // job tiles per pass (64 jobs)
+constexpr int GR_MP = 4;   // pixels per staged group of records
+constexpr int GR_PR = GR_T * 32;
+constexpr int GR_NT = 512; // 8 waves, 256 VGPRs each: a builder's 16 row fragments stay in registers without spills
+constexpr size_t GR_LDS = ((size_t)(GR_T + GR_JT) * 32 * GQ_ROW + GR_JT * 32 /*cls*/ + GR_MP * GR_PR * 5 /*records*/ + 2 * GR_PR /*coverage*/ + 64 /*pixel list*/) * sizeof(float);
+// Per (pair, block of GR_PR poses, chunk of 64 pixels): which pixels does ANY pose of the block cover.  The contraction
+// visits only those (the others contribute nothing to any loss of the block).
+__global__ void rec_mask_kernel(int G, int n_pb, int n_chunks, size_t hw, const RecVid *vid, u64 *mask) {
+  const int c = blockIdx.x % n_chunks, pb = (blockIdx.x / n_chunks) % n_pb, sl = blockIdx.x / (n_chunks * n_pb);
+  const size_t p = (size_t)c * GP_PIX + threadIdx.x;   // 64 threads: one per pixel of the chunk
+  bool any = false;
+  if (p < hw)
+    for (int g = pb * GR_PR; g < min(G, (pb + 1) * GR_PR) && !any; ++g) any = (vid[((size_t)sl * G + g) * hw + p].v2c >> 16) != 0u;
+  const u64 m = __builtin_amdgcn_ballot_w64(any);
+  if (threadIdx.x == 0) mask[blockIdx.x] = m;
+}
+
+template <int D>
+__global__ __launch_bounds__(GR_NT) void grid_mfma_rec_kernel(int hw, int N, int G, int n_chunks, const int32_t *img_idx,
+                                                              const int32_t *order, const int32_t *slot_start,
+                                                              const float *__restrict__ feat, const float *__restrict__ clu,
+                                                              const MeshDesc *meshes, const int32_t *pair_mesh,
+                                                              const RecVid *__restrict__ vid, const float *__restrict__ bary,
+                                                              float *__restrict__ partial, const u64 *__restrict__ pix_mask,
+                                                              int n_pb, int clutter_on) {
+  extern __shared__ __align__(16) float gq_sm[];
+  constexpr int KH = D / 128, T = GR_T, JT = GR_JT, PR = GR_PR, MP = GR_MP;
+  constexpr int NRB = 4 * T, NRA = 4 * JT;  // row fragments per builder / loader thread (rows srow + 8 j of every slab)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, half = lane >> 5;
+  // The pose block is the fastest-varying index: the workgroups that are resident together read the SAME feature rows
+  // (one pixel chunk of one pair's jobs), so the feature tensor streams from HBM about once per sweep of the
+  // chunks instead of once per pose block.
+#ifndef NEMO_GR_PBFAST
+#define NEMO_GR_PBFAST 1
+#endif
+  const int pb = NEMO_GR_PBFAST ? (int)(blockIdx.x % n_pb) : (int)(blockIdx.x / (gridDim.x / n_pb));
+  const int xc = NEMO_GR_PBFAST ? (int)(blockIdx.x / n_pb) : (int)(blockIdx.x % (gridDim.x / n_pb));
+  const int sl = xc / n_chunks, c = xc % n_chunks;
+  const int js = slot_start[sl], ns = slot_start[sl + 1] - js;
+  if (ns == 0) return;
+  const int p0 = c * GP_PIX;
+  const int g0 = pb * PR;
+  // the pixels of this chunk that some pose of this block covers, in ascending order
+  const u64 pmask = pix_mask[((size_t)sl * n_pb + pb) * n_chunks + c];
+  const int npl = __builtin_popcountll(pmask);
+  if (npl == 0) {
+    const int ng = min(PR, G - g0);
+    for (int k = tid; k < ns * ng; k += GR_NT) partial[((size_t)c * N + order[js + k / ng]) * G + g0 + k % ng] = 0.0f;
+    return;
+  }
+  const gf32p bank = as_global(meshes[pair_mesh[sl]].bank);
+  float *As = gq_sm, *Bs = gq_sm + JT * 32 * GQ_ROW, *cls = gq_sm + (T + JT) * 32 * GQ_ROW;
+  uint32_t *mv01 = (uint32_t *)(cls + JT * 32), *mv2c = mv01 + MP * PR;   // records of MP listed pixels x PR poses
+  float *mb = (float *)(mv2c + MP * PR);                               // [MP * PR][3]
+  int *bcov = (int *)(mb + MP * PR * 3);                               // [2][PR]: does pose row r cover the pixel (by list parity)
+  int *plist = bcov + 2 * PR;                                          // [64] listed pixels (offsets inside the chunk)
+  if (tid < 64 && ((pmask >> tid) & 1ull)) plist[__builtin_popcountll(pmask & ((1ull << tid) - 1ull))] = tid;
+  const int jt = wave >> 2, pt = wave & 3;                             // wave w multiplies job tile w / 4 with pose tile w % 4
+  const bool loader = wave < 4;                                         // waves 0-3: HBM side; waves 4-7: pose rows
+  const int t2 = tid & 255, srow = t2 >> 5, sc4 = t2 & 31;             // this thread stages rows srow + 8 j (j < 4) of each slab
+  const int n_stage = npl * KH;                                         // stage s = (listed pixel s / KH, feature half s % KH)
+  const gf4p feat4 = (gf4p)as_global(feat);
+  __syncthreads();
+  for (int tg = 0; tg < ns; tg += JT * 32) {
+    // ---- per-pass offsets (in 16-byte units: the feature tensor may exceed 4 GiB, its 16-byte index does not)
+    uint32_t ro[NRA];   // loaders: feature rows of the pass's jobs at pixel 0 of the chunk
+#pragma unroll
+    for (int k = 0; k < NRA; ++k) {
+      const int job = order[js + min(tg + (k >> 2) * 32 + srow + 8 * (k & 3), ns - 1)];
+      ro[k] = (uint32_t)((((size_t)(img_idx ? img_idx[job] : job) * hw + p0) * D) >> 2) + (uint32_t)sc4;
+    }
+    const float *clp = nullptr;
+    if (clutter_on && tid < JT * 32) {
+      const int job = order[js + min(tg + tid, ns - 1)];
+      clp = clu + (size_t)(img_idx ? img_idx[job] : job) * hw + p0;
+    }
+    // records are staged MP listed pixels at a time by the loaders: thread t2 owns (pose row, list slot) items t2, t2 + 256
+    RecVid mvr[2];
+    float mbr[2][3];
+    size_t mbase[2];       // record index of (this thread's pose row, pixel 0 of the chunk)
+    int mlds[2], mpxs[2];  // LDS slot and position-in-group of the thread's two items
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int it = t2 + 256 * u, mrow = it / MP;
+      mpxs[u] = it % MP;
+      mbase[u] = ((size_t)sl * G + min(g0 + mrow, G - 1)) * hw + p0;
+      mlds[u] = mpxs[u] * PR + mrow;
+    }
+    auto meta_fetch = [&](int grp) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const size_t idx = mbase[u] + plist[min(grp * MP + mpxs[u], npl - 1)];
+        mvr[u] = vid[idx];
+        mbr[u][0] = bary[3 * idx]; mbr[u][1] = bary[3 * idx + 1]; mbr[u][2] = bary[3 * idx + 2];
+      }
+    };
+    auto meta_store = [&]() {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        mv01[mlds[u]] = mvr[u].v01; mv2c[mlds[u]] = mvr[u].v2c;
+        mb[mlds[u] * 3] = mbr[u][0]; mb[mlds[u] * 3 + 1] = mbr[u][1]; mb[mlds[u] * 3 + 2] = mbr[u][2];
+      }
+    };
+    f16v lsum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lsum[r] = 0.0f;
+    // Row fragments this thread writes to LDS at the start of the next stage: the NRA feature rows a loader fetched,
+    // or the NRB pose rows a builder built, during this one.
+    f4 st[NRB];
+    float clv = 0.0f;
+    auto fetch = [&](int s) {   // loaders
+      const int px = plist[s / KH], kh = s % KH;
+#pragma unroll
+      for (int k = 0; k < NRA; ++k) st[k] = feat4[ro[k] + (uint32_t)(px * (D / 4) + kh * 32)];
+      if (kh == 0 && clp) clv = clp[px];
+    };
+    // builders: a stage's rows are built in three rounds, one per vertex of the covering face: round_issue starts the
+    // bank-row loads of all NRB fragments, round_take folds them into st[] once they have landed
+    f4 m[NRB];
+    float bw[NRB];
+    auto round_issue = [&](int pos, int kh, int v) {
+      // one variable LDS index per stage (list position in its group and this thread's row offset); the row of
+      // fragment k is a compile-time distance from it, so the reads below carry immediate offsets
+      const int base = (pos % MP) * PR + srow;
+      const uint32_t *a_ = mv01 + base, *b_ = mv2c + base;
+      const float *w_ = mb + 3 * base;
+      int *c_ = bcov + (pos & 1) * PR + srow;
+#pragma unroll
+      for (int k = 0; k < NRB; ++k) {
+        const int ro_ = (k >> 2) * 32 + 8 * (k & 3);   // constant
+        const uint32_t b = b_[ro_];
+        const bool cov = (b >> 16) != 0u;
+        const uint32_t vv = v == 2 ? (b & 0xffffu) : (v == 0 ? (a_[ro_] & 0xffffu) : (a_[ro_] >> 16));
+        bw[k] = cov ? w_[3 * ro_ + v] : 0.0f;
+        m[k] = f4{0.f, 0.f, 0.f, 0.f};
+#ifndef NEMO_GR_ABL
+#define NEMO_GR_ABL 0
+#endif
+        if (cov && !(NEMO_GR_ABL & 1)) m[k] = *(gf4p)(bank + (vv * (uint32_t)D + (uint32_t)(kh * 128 + sc4 * 4)));
+        if (v == 0 && kh == 0 && sc4 == 0) c_[ro_] = cov ? 1 : 0;
+      }
+    };
+    auto round_take = [&](int v) {
+#pragma unroll
+      for (int k = 0; k < NRB; ++k) st[k] = v == 0 ? bw[k] * m[k] : st[k] + bw[k] * m[k];
+    };
+    // ---- prologue: records of the first listed pixels, the feature rows and the pose rows of stage 0
+    if (loader) {
+      meta_fetch(0);
+      meta_store();
+      fetch(0);
+    }
+    __syncthreads();
+    if (!loader) {
+#pragma unroll
+      for (int v = 0; v < 3; ++v) { round_issue(0, 0, v); round_take(v); }
+    }
+    f16v acc;
+    for (int s = 0; s < n_stage; ++s) {
+      const int pos = s / KH, kh = s - pos * KH;
+      const int sn = s + 1, posn = sn / KH, khn = sn - posn * KH;   // the stage being prepared by the builders
+      if (kh == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+      }
+      __syncthreads();  // the previous stage has been consumed
+      if (loader) {
+        float *dst = As + srow * GQ_ROW + sc4 * 4;
+#pragma unroll
+        for (int k = 0; k < NRA; ++k) *(f4 *)&dst[((k >> 2) * 32 + 8 * (k & 3)) * GQ_ROW] = st[k];
+        if (kh == 0 && tid < JT * 32) cls[tid] = clv;
+        // the records of the group the NEXT listed pixel belongs to, when it opens a group (fetched one stage earlier)
+        if (khn == 0 && posn < npl && posn % MP == 0) meta_store();
+      } else {
+        float *dst = Bs + srow * GQ_ROW + sc4 * 4;
+#pragma unroll
+        for (int k = 0; k < NRB; ++k) *(f4 *)&dst[((k >> 2) * 32 + 8 * (k & 3)) * GQ_ROW] = st[k];
+      }
+      __syncthreads();
+      const bool more = sn < n_stage;
+      if (loader) {
+        if (more) fetch(sn);
+        // records two listed pixels ahead: they are stored one stage before the builders read them
+        const int s2 = s + 2, pos2 = s2 / KH;
+        if (s2 < n_stage && s2 - pos2 * KH == 0 && pos2 % MP == 0) meta_fetch(pos2 / MP);
+      }
+      // does any of this wave's 32 poses cover the pixel?  (wave-uniform)
+      const bool live = !(NEMO_GR_ABL & 2) && __builtin_amdgcn_ballot_w64(bcov[(pos & 1) * PR + pt * 32 + i] != 0) != 0ull;
+      const float *ap = As + (jt * 32 + i) * GQ_ROW + 4 * half, *bp = Bs + (pt * 32 + i) * GQ_ROW + 4 * half;
+      // one 16-byte operand step = 4 of the stage's 64 matrix instructions; the operands of the next step are read from
+      // LDS before this step's instructions are issued (two waves per SIMD do not hide that latency by themselves)
+      f4 a_cur = f4{0.f, 0.f, 0.f, 0.f}, b_cur = a_cur;
+      if (live) { a_cur = *(const f4 *)ap; b_cur = *(const f4 *)bp; }
+      auto mfma_group = [&](int q) {
+        if (live) {
+          const f4 a = a_cur, b = b_cur;
+          if (q + 1 < 16) { a_cur = *(const f4 *)(ap + 8 * (q + 1)); b_cur = *(const f4 *)(bp + 8 * (q + 1)); }
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
+      };
+      const bool build = !loader && more;
+      // three rounds between the sixteen operand steps
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {
+        if (build) round_issue(posn, khn, v);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 5 * v; q < 5 * v + 5; ++q) mfma_group(q);
+        __builtin_amdgcn_sched_barrier(0);
+        if (build) round_take(v);
+      }
+      mfma_group(15);
+      // C/D layout: column = lane & 31 (pose), row = (r & 3) + 8 * (r >> 2) + 4 * half (job of the tile)
+      if (kh == KH - 1 && live) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const f4 cv = *(const f4 *)&cls[jt * 32 + 8 * k + 4 * half];
+          const float cc[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float o = acc[4 * k + r];
+            lsum[4 * k + r] += clutter_on ? (fmaxf(o, cc[r]) - fmaxf(0.0f, cc[r])) : o;
+          }
+        }
+      }
+    }
+    {
+      const int g = g0 + pt * 32 + i;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int jrow = tg + jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (jrow < ns && g < G) partial[((size_t)c * N + order[js + jrow]) * G + g] = lsum[r];
+      }
+    }
+    __syncthreads();  // the next pass restages the LDS
+  }
+}
+
 // loss[n][g] = K_n - (1/hw) * sum over chunks (chunk order), K_n = 1 + mean(min(clu, 0)) (loss_constant).
 __global__ __launch_bounds__(256) void grid_finish_kernel(int hw, float inv_hw, int N, int G, int n_chunks,
                                                           const int32_t *img_idx, const int32_t *job_slot,

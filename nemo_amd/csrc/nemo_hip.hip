@@ -56,6 +56,9 @@ struct nemo_ctx {
   // pre-rendered grid (nemo_grid_prerender)
   int32_t *d_pre_slot, *d_pre_cnt, *d_pre_pairs;
   uint32_t *d_pre_list;
+  RecVid *d_pre_vid;  // records [pairs][G][h*w] (vertex ids + covered flag) and their barycentrics [..][3] for the
+  float *d_pre_bary;  // record-based matrix-core grid search (dense grids: no materialised renders), or null
+  u64 *d_pre_mask;    // [pairs][pose blocks of GR_PR][pixel chunks]: pixels covered by any pose of the block
   float *d_pre_maps;  // dense renders [pairs][pre_block][h*w][D] for the MFMA grid search, or null (no store / large meshes)
   int pre_block;      // poses per pair held by d_pre_maps: pre_G (whole grid resident) or a block of it (rendered per call)
   // block render scratch (job = (pair, pose of the block)); in the resident case freed once the maps are rendered
@@ -79,6 +82,7 @@ struct nemo_ctx {
   int n_cu;              // its compute-unit count (cached: hipGetDeviceProperties is slow)
   // environment switches, read ONCE in nemo_ctx_create (hot calls never call getenv)
   int env_grid_no_mfma, env_solve_stagger, env_solve_order, env_solve_affinity, env_slot_identity;
+  int env_grid_rec_min;  // NEMO_GRID_REC_MIN_POSES: grids with at least this many poses use the record store (0: never)
   double env_prerender_map_gb;
   char err[512];
 };
@@ -316,6 +320,8 @@ int nemo_ctx_create(const nemo_config *cfg, nemo_ctx **out) {
   SET_LDS_B(interp_bwd_kernel, 256, false); SET_LDS_B(interp_bwd_kernel, 256, true);
 #undef SET_LDS_B
 #undef SET_LDS
+  hipFuncSetAttribute((const void *)grid_mfma_rec_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GR_LDS);
+  hipFuncSetAttribute((const void *)grid_mfma_rec_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GR_LDS);
   hipFuncSetAttribute((const void *)feature_head_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
   hipFuncSetAttribute((const void *)feature_head_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
   hipFuncSetAttribute((const void *)clutter_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CK_ROWS * (128 + 4) * 4);
@@ -333,6 +339,7 @@ int nemo_ctx_create(const nemo_config *cfg, nemo_ctx **out) {
   ctx->env_solve_order = env_int("NEMO_SOLVE_ORDER", 1);
   ctx->env_solve_affinity = env_int("NEMO_SOLVE_AFFINITY", 1);
   ctx->env_slot_identity = env_int("NEMO_SLOT_ORDER", 1) == 0;
+  ctx->env_grid_rec_min = env_int("NEMO_GRID_REC_MIN_POSES", 512);
   {
     const char *v = getenv("NEMO_PRERENDER_MAP_GB");
     ctx->env_prerender_map_gb = v ? atof(v) : 48.0;
@@ -400,6 +407,7 @@ int nemo_ctx_destroy(nemo_ctx *ctx) {
   hipFree(ctx->d_counter);
   hipFree(ctx->d_adam);
   hipFree(ctx->d_pre_slot); hipFree(ctx->d_pre_cnt); hipFree(ctx->d_pre_pairs); hipFree(ctx->d_pre_list);
+  hipFree(ctx->d_pre_vid); hipFree(ctx->d_pre_bary); hipFree(ctx->d_pre_mask);
   hipFree(ctx->d_pre_maps); hipFree(ctx->d_gs_order); hipFree(ctx->d_gs_start); hipFree(ctx->d_gs_jobslot);
   hipFree(ctx->d_gs_partial); hipFree(ctx->d_gs_work); hipFree(ctx->d_big); hipFree(ctx->d_so);
   for (int i = 0; i < ctx->n_meshes; ++i) hipFree(ctx->d_slot_order[i]);
@@ -550,8 +558,35 @@ int nemo_grid_search(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const i
   const bool store_ok = ctx->pre_pairs > 0 && ctx->pre_G == G && ctx->pre_gridC == d_grid_C && ctx->pre_gridT == d_grid_theta;
   if (store_ok) pre = PreStore{ctx->d_pre_slot, ctx->d_pre_cnt, ctx->d_pre_list, (size_t)ctx->cfg.win_h * ctx->cfg.win_w};
   const bool mfma = store_ok && ctx->d_pre_maps && !ctx->env_grid_no_mfma;
+  const bool rec = store_ok && ctx->d_pre_vid && !ctx->env_grid_no_mfma;
   const int32_t *d_work = nullptr;
-  if (mfma) {
+  if (rec) {
+    // dense grids: the pose operand is built from the record store, nothing is rendered or materialised per call
+    const int hw = ctx->cfg.win_h * ctx->cfg.win_w, n_chunks = (hw + GP_PIX - 1) / GP_PIX;
+    const size_t need_partial = (size_t)n_chunks * N * G;
+    if ((size_t)N > ctx->gs_jobs_cap || need_partial > ctx->gs_partial_cap)
+      return fail(ctx, NEMO_ERR_STATE, "nemo_grid_search: workspace reserved for %zu jobs / %zu partial sums, this call needs "
+                  "%d / %zu: call nemo_workspace_reserve(ctx, >= %d, >= %d) first", ctx->gs_jobs_cap, ctx->gs_partial_cap, N,
+                  need_partial, N, G);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(grid_group_kernel, dim3(1), dim3(1024), 0, st, N, d_mesh_idx, d_grid_idx, ctx->d_pre_slot,
+                       ctx->pre_pairs, ctx->d_gs_order, ctx->d_gs_start, ctx->d_gs_jobslot, ctx->d_gs_work);
+    d_work = ctx->d_gs_work;
+    const int con = (ctx->cfg.clutter && d_clu) ? 1 : 0;
+    const int n_pb = (G + GR_PR - 1) / GR_PR;
+    const dim3 grd((unsigned)((size_t)ctx->pre_pairs * n_chunks * n_pb)), blk(GR_NT);
+    if (ctx->cfg.feat_dim == 128)
+      hipLaunchKernelGGL((grid_mfma_rec_kernel<128>), grd, blk, GR_LDS, st, hw, N, G, n_chunks, d_img_idx, ctx->d_gs_order,
+                         ctx->d_gs_start, d_feat, d_clu, (const MeshDesc *)ctx->d_meshes, (const int32_t *)ctx->d_pre_pairs,
+                         (const RecVid *)ctx->d_pre_vid, (const float *)ctx->d_pre_bary, ctx->d_gs_partial, (const u64 *)ctx->d_pre_mask, n_pb, con);
+    else
+      hipLaunchKernelGGL((grid_mfma_rec_kernel<256>), grd, blk, GR_LDS, st, hw, N, G, n_chunks, d_img_idx, ctx->d_gs_order,
+                         ctx->d_gs_start, d_feat, d_clu, (const MeshDesc *)ctx->d_meshes, (const int32_t *)ctx->d_pre_pairs,
+                         (const RecVid *)ctx->d_pre_vid, (const float *)ctx->d_pre_bary, ctx->d_gs_partial, (const u64 *)ctx->d_pre_mask, n_pb, con);
+    hipLaunchKernelGGL(grid_finish_kernel, dim3(N), dim3(256), 0, st, hw, ctx->P.inv_hw, N, G, n_chunks, d_img_idx,
+                       ctx->d_gs_jobslot, d_clu, ctx->d_gs_partial, ctx->d_pre_cnt, d_losses, ctx->d_counter, con);
+    HIP_TRY(ctx, hipGetLastError());
+  } else if (mfma) {
     // matrix-core path over the dense pre-rendered maps; jobs without a stored pair fall through to grid_kernel
     const int hw = ctx->cfg.win_h * ctx->cfg.win_w, n_chunks = (hw + GP_PIX - 1) / GP_PIX;
     const size_t need_partial = (size_t)n_chunks * N * G;
@@ -624,12 +659,15 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
                         const int32_t *h_pair_mesh, const int32_t *h_pair_grid, int32_t n_pairs, void *stream) {
   if (!ctx) return fail(nullptr, NEMO_ERR_ARG, "nemo_grid_prerender: null ctx");
   hipFree(ctx->d_pre_slot); hipFree(ctx->d_pre_cnt); hipFree(ctx->d_pre_pairs); hipFree(ctx->d_pre_list);
-  hipFree(ctx->d_pre_maps);
+  hipFree(ctx->d_pre_maps); hipFree(ctx->d_pre_vid); hipFree(ctx->d_pre_bary); hipFree(ctx->d_pre_mask);
+  ctx->d_pre_mask = nullptr;
   free_block_scratch(ctx, false);
   ctx->pre_block = 0;
   ctx->d_pre_slot = ctx->d_pre_cnt = ctx->d_pre_pairs = nullptr;
   ctx->d_pre_list = nullptr;
   ctx->d_pre_maps = nullptr;
+  ctx->d_pre_vid = nullptr;
+  ctx->d_pre_bary = nullptr;
   ctx->pre_pairs = 0;
   if (n_pairs == 0) return NEMO_OK;  // store dropped
   if (!d_grid_C || !d_grid_theta || !h_pair_mesh || !h_pair_grid || n_pairs < 0 || G <= 0 || n_grids <= 0)
@@ -667,6 +705,61 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
   // fit, they are rendered here, once; otherwise the buffer holds a BLOCK of poses (a multiple of 32, the matrix-core
   // pose tile) and nemo_grid_search renders block after block into it.  Large (BIG) meshes render at most
   // BIG_MAX_BLOCKS (pair, pose) jobs per launch (one table slice per workgroup), which bounds their block.
+  // Record store (dense grids): per (pair, pose, pixel) three vertex ids + covered flag and three barycentrics, 20 bytes,
+  // from which grid_mfma_rec_kernel builds the rendered rows on the fly.  Rendered here in slices of poses through a
+  // temporary pix_to_face / bary buffer (campos -> rasterize -> pack).  Ordinary (LDS-table) meshes only.
+  if (n_pairs <= GP_MAX_PAIRS && !ctx->P.big && !ctx->env_grid_no_mfma && ctx->env_grid_rec_min > 0 && G >= ctx->env_grid_rec_min &&
+      (double)n_pairs * G * stride * 20.0 <= ctx->env_prerender_map_gb * 1073741824.0) {
+    const size_t n_rec = (size_t)n_pairs * G * stride;
+    const int n_chunks = (int)((stride + GP_PIX - 1) / GP_PIX);
+    long gb = (long)((2048.0 * 1048576.0) / ((double)n_pairs * stride * 16.0));   // about 2 GiB of scratch per slice
+    if (gb < 1) gb = 1;
+    if (gb > G) gb = G;
+    const size_t jobs = (size_t)n_pairs * gb;
+    hipError_t e = hipMalloc((void **)&ctx->d_pre_vid, n_rec * sizeof(RecVid));
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_pre_bary, n_rec * 12);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_blk_mesh, jobs * 4);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_blk_gidx, jobs * 4);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_blk_C, jobs * 12);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_blk_t, jobs * 4);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_blk_R, jobs * 36);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_blk_T, jobs * 12);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_blk_p2f, jobs * stride * 4);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_blk_bary, jobs * stride * 12);
+    hipStream_t st = (hipStream_t)stream;
+    for (long g0 = 0; e == hipSuccess && g0 < G; g0 += gb) {
+      const int nb = (int)(G - g0 < gb ? G - g0 : gb);
+      const size_t nj = (size_t)n_pairs * nb;
+      hipLaunchKernelGGL(block_jobs_kernel, dim3((unsigned)((nj + 255) / 256)), dim3(256), 0, st, n_pairs, G, (int)g0, nb,
+                         (const int32_t *)ctx->d_pre_pairs, (const int32_t *)(ctx->d_pre_pairs + n_pairs), ctx->d_blk_mesh, ctx->d_blk_gidx);
+      hipLaunchKernelGGL(gather_pose_kernel, dim3((unsigned)((nj + 255) / 256)), dim3(256), 0, st, (int)nj,
+                         (const int32_t *)ctx->d_blk_gidx, d_grid_C, d_grid_theta, ctx->d_blk_C, ctx->d_blk_t);
+      hipLaunchKernelGGL(campos_kernel, dim3((unsigned)((nj + 63) / 64)), dim3(64), 0, st, (const float *)ctx->d_blk_C,
+                         (const float *)ctx->d_blk_t, (const float *)nullptr, (int)nj, ctx->d_blk_R, ctx->d_blk_T);
+      LAUNCH_PB(raster_kernel, dim3((unsigned)nj), st, ctx->P, ctx->d_meshes, (const int32_t *)ctx->d_blk_mesh,
+                (const float *)ctx->d_blk_R, (const float *)ctx->d_blk_T, ctx->d_blk_p2f, ctx->d_blk_bary, (float *)nullptr);
+      const size_t npix = nj * stride;
+      hipLaunchKernelGGL(pack_rec_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, npix, stride, (int)G, (int)g0, nb,
+                         (const MeshDesc *)ctx->d_meshes, (const int32_t *)ctx->d_blk_mesh, (const int32_t *)ctx->d_blk_p2f,
+                         (const float *)ctx->d_blk_bary, ctx->d_pre_vid, ctx->d_pre_bary);
+      e = hipGetLastError();
+    }
+    const int n_pb = (int)((G + GR_PR - 1) / GR_PR);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_pre_mask, sizeof(u64) * (size_t)n_pairs * n_pb * n_chunks);
+    if (e == hipSuccess) {  // per (pair, pose block, pixel chunk): the pixels any pose of the block covers
+      hipLaunchKernelGGL(rec_mask_kernel, dim3((unsigned)((size_t)n_pairs * n_pb * n_chunks)), dim3(64), 0, st, (int)G, n_pb, n_chunks,
+                         stride, (const RecVid *)ctx->d_pre_vid, ctx->d_pre_mask);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    free_block_scratch(ctx, false);
+    if (e != hipSuccess) {
+      hipFree(ctx->d_pre_vid); hipFree(ctx->d_pre_bary); hipFree(ctx->d_pre_mask);
+      ctx->d_pre_vid = nullptr; ctx->d_pre_bary = nullptr; ctx->d_pre_mask = nullptr;
+      return hip_fail(ctx, e, "nemo_grid_prerender: record store");
+    }
+    return NEMO_OK;
+  }
   if (n_pairs <= GP_MAX_PAIRS) {
     const double budget = ctx->env_prerender_map_gb * 1073741824.0;
     const size_t D = (size_t)ctx->cfg.feat_dim;

@@ -1282,8 +1282,11 @@ def test_dense_grid_tiled_over_pose_blocks(oracle, monkeypatch):
     feats, clus = _dev(np.concatenate([a.feats, b.feats])), _dev(np.concatenate([a.clus, b.clus]))
     mesh = _dev([0, 0, 1, 1], torch.int32)
     out = {}
-    for mode, gb in (('tiled', '0.15'), ('resident', '48')):
+    for mode, gb in (('tiled', '0.15'), ('resident', '48'), ('records', '48')):
         monkeypatch.setenv('NEMO_PRERENDER_MAP_GB', gb)       # read once, at context creation
+        # 'records': no dense maps at all -- the pose operand is built from the 20-byte record store (dense grids take
+        # this path from 512 poses on; forced here)
+        monkeypatch.setenv('NEMO_GRID_REC_MIN_POSES', '1' if mode == 'records' else '0')
         eng = PoseEngine(a.geo.S, (a.geo.h, a.geo.w), a.D)
         eng.register_mesh(a.verts, a.faces, a.bank)
         eng.register_mesh(b.verts, b.faces, b.bank)
@@ -1295,12 +1298,37 @@ def test_dense_grid_tiled_over_pose_blocks(oracle, monkeypatch):
         assert torch.cuda.mem_get_info()[0] >= free0 - (8 << 20)          # block rendering allocates nothing (torch outputs aside)
     # 2 pairs x 1536 px x 128 x 4 B = 1.5 MB per pose: 0.15 GB hold 102 -> 96 poses per block, 288 poses = 3 blocks
     assert torch.equal(out['tiled'][3], out['resident'][3]) and torch.equal(out['tiled'][2], out['resident'][2])
+    assert torch.equal(out['records'][3], out['resident'][3]) and torch.equal(out['records'][2], out['resident'][2])
     best, losses = out['tiled'][2].cpu().numpy(), out['tiled'][3].cpu().numpy()
     for k in range(4):
         sc, (gC, gth) = ((a, grids[0]) if k < 2 else (b, grids[1]))
         bo, lo = oracle.grid_search(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[k % 2], sc.clus[k % 2], gC, gth)
         assert np.abs(losses[k] - lo).max() <= REL * np.abs(lo).max()
         assert best[k] == bo
+
+
+@pytest.mark.parametrize('D,clutter', [(128, False), (256, True)])
+def test_dense_grid_record_store(oracle, monkeypatch, D, clutter):
+    """The record-based matrix-core grid search (no materialised renders) on its own: 256-d features (two feature
+    halves per pixel) and the loss without clutter, more jobs than one 64-job pass, a window whose last pixel chunk
+    is partial, against the oracle."""
+    monkeypatch.setenv('NEMO_GRID_REC_MIN_POSES', '1')
+    sc = make_scene(image_hw=(136, 200), number_vertices=150, n_img=3, seed=43, D=D, clutter=clutter)
+    assert (sc.cfg.h * sc.cfg.w) % 64 != 0
+    eng = _engine(sc)
+    gC, gth = syn.pose_grid(sc.distance, n_azim=12, n_elev=4, n_theta=3)
+    dC, dth = _dev(gC[None]), _dev(gth[None])
+    feats, clus = _dev(sc.feats), (_dev(sc.clus) if clutter else None)
+    n = 70
+    img = _dev(np.arange(n) % 3, torch.int32)
+    eng.grid_prerender(dC, dth, [(0, 0)])
+    C0, th0, best, losses = eng.grid_search(feats, clus, dC, dth, img_idx=img)
+    best, losses = best.cpu().numpy(), losses.cpu().numpy()
+    assert np.isfinite(losses).all()
+    for i in range(3):
+        bo, lo = oracle.grid_search(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[i], sc.clus[i] if clutter else None, gC, gth)
+        for k in range(i, n, 3):
+            assert np.abs(losses[k] - lo).max() <= REL * np.abs(lo).max() and best[k] == bo
 
 
 def test_large_mesh_256d_double_resolution(oracle):
