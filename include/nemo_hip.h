@@ -155,10 +155,23 @@ int nemo_grid_search(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const i
  * (mesh, grid) pair and kept by the context; nemo_grid_search then skips projection-independent work
  * for jobs whose pair is stored (others are rendered on the fly; results are the same either way).
  * The store is tied to the two device pointers and G and is dropped by n_pairs == 0 or the next call.
- * h_pair_mesh / h_pair_grid are HOST arrays.  Setup call: allocates n_pairs*G*win_h*win_w*4 bytes. */
+ * h_pair_mesh / h_pair_grid are HOST arrays.  Setup call: allocates.
+ * What is kept (all three give the same losses; the matrix-core forms bit for bit the same as each other):
+ *   - always: per (pair, pose) the list of covered pixels with their faces, n_pairs*G*win_h*win_w*4 bytes;
+ *   - the operand of the matrix-core grid search, within NEMO_PRERENDER_MAP_GB (default 48) of device memory:
+ *     1 the dense renders f32[pair][G][win_h*win_w][D] when they fit, rendered here once;
+ *     3 else, for meshes whose tables fit the LDS, a record per (pair, pose, pixel) -- three 16-bit vertex ids, a covered
+ *       flag, three barycentrics, 20 bytes -- from which nemo_grid_search builds the rendered rows on the fly in LDS
+ *       (BASELINE config 4, 12 classes x 9720 poses: 19 GB of records instead of 478 GB of renders);
+ *     2 else a buffer for a block of poses (a multiple of 32) that nemo_grid_search re-renders block after block.
+ *   NEMO_GRID_RECORDS=1 in the environment (at nemo_ctx_create) prefers 3 whenever the records fit, =0 never uses it;
+ *   NEMO_GRID_NO_MFMA=1 keeps the list path only.  nemo_grid_store_kind reports which form the context holds. */
 int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_grid_theta, int32_t n_grids,
                         int32_t G, const int32_t *h_pair_mesh, const int32_t *h_pair_grid, int32_t n_pairs,
                         void *stream);
+/* 0 = no matrix-core operand stored (lists only, or nothing pre-rendered), 1 = resident dense renders, 2 = pose-block
+ * buffer, 3 = record store.  A query of this library's own state; the reference has no counterpart. */
+int nemo_grid_store_kind(const nemo_ctx *ctx);
 
 /* The 300-step solve (code/MeshPoseSolveAll.py:227-250): render, score, loss,
  * backward and Adam on (Cx,Cy,Cz,theta) fused in one persistent launch, one

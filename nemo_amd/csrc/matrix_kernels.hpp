@@ -244,10 +244,14 @@ __global__ void pack_rec_kernel(size_t npix, size_t hw, int G, int g0, int gb, c
 
 constexpr int GR_T = 4;    // pose tiles per workgroup (128 poses)
 constexpr int GR_JT = 2;   // job tiles per pass (64 jobs)
-constexpr int GR_MP = 4;   // pixels per staged group of records
+constexpr int GR_MP = 4;   // listed pixels per staged group of records
 constexpr int GR_PR = GR_T * 32;
-constexpr int GR_NT = 512; // 8 waves, 256 VGPRs each: a builder's 16 row fragments stay in registers without spills
-constexpr size_t GR_LDS = ((size_t)(GR_T + GR_JT) * 32 * GQ_ROW + GR_JT * 32 /*cls*/ + GR_MP * GR_PR * 5 /*records*/ + 2 * GR_PR /*coverage*/ + 64 /*pixel list*/) * sizeof(float);
+constexpr int GR_NT = 1024; // 16 waves: 8 matrix waves, 8 staging waves
+constexpr int GR_KS = 64;  // features per stage: a stage is (listed pixel, 64-feature slice)
+constexpr int GR_ROW = GR_KS + 4;  // padded LDS row: the 16-byte operand reads of a 16-lane group are conflict-free
+constexpr int GR_BUF = (GR_T + GR_JT) * 32 * GR_ROW;  // floats of one stage buffer (job rows, then pose rows)
+constexpr size_t GR_LDS = ((size_t)2 * GR_BUF + 2 * GR_JT * 32 /*cls*/ + 2 * GR_MP * GR_PR * 5 /*records*/ + 2 * GR_PR /*coverage*/ +
+                           64 /*pixel list*/ + GR_JT * 32 /*job ids*/) * sizeof(float);
 // Per (pair, block of GR_PR poses, chunk of 64 pixels): which pixels does ANY pose of the block cover.  The contraction
 // visits only those (the others contribute nothing to any loss of the block).
 __global__ void rec_mask_kernel(int G, int n_pb, int n_chunks, size_t hw, const RecVid *vid, u64 *mask) {
@@ -269,18 +273,15 @@ __global__ __launch_bounds__(GR_NT) void grid_mfma_rec_kernel(int hw, int N, int
                                                               float *__restrict__ partial, const u64 *__restrict__ pix_mask,
                                                               int n_pb, int clutter_on) {
   extern __shared__ __align__(16) float gq_sm[];
-  constexpr int KH = D / 128, T = GR_T, JT = GR_JT, PR = GR_PR, MP = GR_MP;
-  constexpr int NRB = 4 * T, NRA = 4 * JT;  // row fragments per builder / loader thread (rows srow + 8 j of every slab)
+  constexpr int NKS = D / GR_KS, T = GR_T, JT = GR_JT, PR = GR_PR, MP = GR_MP, ROW = GR_ROW;
+  constexpr int NRB = T, NRA = JT;  // row fragments per staging thread (rows srow + 32 k of the pose / the job slab)
+  constexpr int GS = MP * NKS;              // stages per group of records
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 31, half = lane >> 5;
   // The pose block is the fastest-varying index: the workgroups that are resident together read the SAME feature rows
   // (one pixel chunk of one pair's jobs), so the feature tensor streams from HBM about once per sweep of the
   // chunks instead of once per pose block.
-#ifndef NEMO_GR_PBFAST
-#define NEMO_GR_PBFAST 1
-#endif
-  const int pb = NEMO_GR_PBFAST ? (int)(blockIdx.x % n_pb) : (int)(blockIdx.x / (gridDim.x / n_pb));
-  const int xc = NEMO_GR_PBFAST ? (int)(blockIdx.x / n_pb) : (int)(blockIdx.x % (gridDim.x / n_pb));
+  const int pb = (int)(blockIdx.x % n_pb), xc = (int)(blockIdx.x / n_pb);
   const int sl = xc / n_chunks, c = xc % n_chunks;
   const int js = slot_start[sl], ns = slot_start[sl + 1] - js;
   if (ns == 0) return;
@@ -295,190 +296,201 @@ __global__ __launch_bounds__(GR_NT) void grid_mfma_rec_kernel(int hw, int N, int
     return;
   }
   const gf32p bank = as_global(meshes[pair_mesh[sl]].bank);
-  float *As = gq_sm, *Bs = gq_sm + JT * 32 * GQ_ROW, *cls = gq_sm + (T + JT) * 32 * GQ_ROW;
-  uint32_t *mv01 = (uint32_t *)(cls + JT * 32), *mv2c = mv01 + MP * PR;   // records of MP listed pixels x PR poses
-  float *mb = (float *)(mv2c + MP * PR);                               // [MP * PR][3]
-  int *bcov = (int *)(mb + MP * PR * 3);                               // [2][PR]: does pose row r cover the pixel (by list parity)
-  int *plist = bcov + 2 * PR;                                          // [64] listed pixels (offsets inside the chunk)
+  // LDS: two stage buffers (64 job rows + 128 pose rows of 64 features), so that stage s + 1 is written while the matrix
+  // instructions of stage s read the other buffer -- one barrier per stage, the matrix pipe does not wait for staging
+  float *cls = gq_sm + 2 * GR_BUF;                                      // [2][64] clutter scores of the jobs, by list parity
+  uint32_t *mv01 = (uint32_t *)(cls + 2 * JT * 32), *mv2c = mv01 + 2 * MP * PR;   // [2][MP * PR] records, by group parity
+  float *mb = (float *)(mv2c + 2 * MP * PR);                            // [2][MP * PR][3]
+  int *bcov = (int *)(mb + 2 * MP * PR * 3);                            // [2][PR]: does pose row r cover the pixel (list parity)
+  int *plist = bcov + 2 * PR;                                           // [64] listed pixels (offsets inside the chunk)
+  int *ordl = plist + 64;                                               // [64] job ids of the pass
   if (tid < 64 && ((pmask >> tid) & 1ull)) plist[__builtin_popcountll(pmask & ((1ull << tid) - 1ull))] = tid;
-  const int jt = wave >> 2, pt = wave & 3;                             // wave w multiplies job tile w / 4 with pose tile w % 4
-  const bool loader = wave < 4;                                         // waves 0-3: HBM side; waves 4-7: pose rows
-  const int t2 = tid & 255, srow = t2 >> 5, sc4 = t2 & 31;             // this thread stages rows srow + 8 j (j < 4) of each slab
-  const int n_stage = npl * KH;                                         // stage s = (listed pixel s / KH, feature half s % KH)
+  // Wave roles (two separate loops with the same barrier count, so that the register allocation is the maximum of the
+  // two roles and not their sum):
+  //   waves 0-7, the MATRIX waves: wave w multiplies job tile w / 4 with pose tile w % 4 (two matrix waves per SIMD: the
+  //     one's LDS waits, loss updates and barrier arrival are covered by the other's matrix instructions) and, every MP
+  //     pixels, moves its share of the next group of records HBM -> LDS;
+  //   waves 8-15, the STAGING waves: build the 128 pose rows of the next stage from the records and the bank, and move
+  //     the 64 feature rows of the stage after next HBM -> registers -> LDS.  Their loads are unconditional and in a fixed
+  //     order, so the in-order memory counter lets them wait for the bank rows (L2) without waiting for the feature
+  //     rows (HBM) issued after them.
+  const bool matrix = wave < 8;
+  const int pt = wave & 3, jt = (wave >> 2) & 1;
+  const int t2 = tid - 512, srow = t2 >> 4, sc4 = t2 & 15;              // staging waves: rows srow + 32 k of a slab
+  const int n_stage = npl * NKS;                                         // stage s = (listed pixel s / NKS, slice s % NKS)
   const gf4p feat4 = (gf4p)as_global(feat);
-  __syncthreads();
-  for (int tg = 0; tg < ns; tg += JT * 32) {
-    // ---- per-pass offsets (in 16-byte units: the feature tensor may exceed 4 GiB, its 16-byte index does not)
-    uint32_t ro[NRA];   // loaders: feature rows of the pass's jobs at pixel 0 of the chunk
-#pragma unroll
-    for (int k = 0; k < NRA; ++k) {
-      const int job = order[js + min(tg + (k >> 2) * 32 + srow + 8 * (k & 3), ns - 1)];
-      ro[k] = (uint32_t)((((size_t)(img_idx ? img_idx[job] : job) * hw + p0) * D) >> 2) + (uint32_t)sc4;
-    }
-    const float *clp = nullptr;
-    if (clutter_on && tid < JT * 32) {
-      const int job = order[js + min(tg + tid, ns - 1)];
-      clp = clu + (size_t)(img_idx ? img_idx[job] : job) * hw + p0;
-    }
-    // records are staged MP listed pixels at a time by the loaders: thread t2 owns (pose row, list slot) items t2, t2 + 256
-    RecVid mvr[2];
-    float mbr[2][3];
-    size_t mbase[2];       // record index of (this thread's pose row, pixel 0 of the chunk)
-    int mlds[2], mpxs[2];  // LDS slot and position-in-group of the thread's two items
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int it = t2 + 256 * u, mrow = it / MP;
-      mpxs[u] = it % MP;
-      mbase[u] = ((size_t)sl * G + min(g0 + mrow, G - 1)) * hw + p0;
-      mlds[u] = mpxs[u] * PR + mrow;
-    }
-    auto meta_fetch = [&](int grp) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const size_t idx = mbase[u] + plist[min(grp * MP + mpxs[u], npl - 1)];
-        mvr[u] = vid[idx];
-        mbr[u][0] = bary[3 * idx]; mbr[u][1] = bary[3 * idx + 1]; mbr[u][2] = bary[3 * idx + 2];
-      }
-    };
-    auto meta_store = [&]() {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        mv01[mlds[u]] = mvr[u].v01; mv2c[mlds[u]] = mvr[u].v2c;
-        mb[mlds[u] * 3] = mbr[u][0]; mb[mlds[u] * 3 + 1] = mbr[u][1]; mb[mlds[u] * 3 + 2] = mbr[u][2];
-      }
-    };
-    f16v lsum;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) lsum[r] = 0.0f;
-    // Row fragments this thread writes to LDS at the start of the next stage: the NRA feature rows a loader fetched,
-    // or the NRB pose rows a builder built, during this one.
-    f4 st[NRB];
-    float clv = 0.0f;
-    auto fetch = [&](int s) {   // loaders
-      const int px = plist[s / KH], kh = s % KH;
-#pragma unroll
-      for (int k = 0; k < NRA; ++k) st[k] = feat4[ro[k] + (uint32_t)(px * (D / 4) + kh * 32)];
-      if (kh == 0 && clp) clv = clp[px];
-    };
-    // builders: a stage's rows are built in three rounds, one per vertex of the covering face: round_issue starts the
-    // bank-row loads of all NRB fragments, round_take folds them into st[] once they have landed
-    f4 m[NRB];
-    float bw[NRB];
-    auto round_issue = [&](int pos, int kh, int v) {
-      // one variable LDS index per stage (list position in its group and this thread's row offset); the row of
-      // fragment k is a compile-time distance from it, so the reads below carry immediate offsets
-      const int base = (pos % MP) * PR + srow;
-      const uint32_t *a_ = mv01 + base, *b_ = mv2c + base;
-      const float *w_ = mb + 3 * base;
-      int *c_ = bcov + (pos & 1) * PR + srow;
-#pragma unroll
-      for (int k = 0; k < NRB; ++k) {
-        const int ro_ = (k >> 2) * 32 + 8 * (k & 3);   // constant
-        const uint32_t b = b_[ro_];
-        const bool cov = (b >> 16) != 0u;
-        const uint32_t vv = v == 2 ? (b & 0xffffu) : (v == 0 ? (a_[ro_] & 0xffffu) : (a_[ro_] >> 16));
-        bw[k] = cov ? w_[3 * ro_ + v] : 0.0f;
-        m[k] = f4{0.f, 0.f, 0.f, 0.f};
 #ifndef NEMO_GR_ABL
 #define NEMO_GR_ABL 0
 #endif
-        if (cov && !(NEMO_GR_ABL & 1)) m[k] = *(gf4p)(bank + (vv * (uint32_t)D + (uint32_t)(kh * 128 + sc4 * 4)));
-        if (v == 0 && kh == 0 && sc4 == 0) c_[ro_] = cov ? 1 : 0;
-      }
-    };
-    auto round_take = [&](int v) {
-#pragma unroll
-      for (int k = 0; k < NRB; ++k) st[k] = v == 0 ? bw[k] * m[k] : st[k] + bw[k] * m[k];
-    };
-    // ---- prologue: records of the first listed pixels, the feature rows and the pose rows of stage 0
-    if (loader) {
-      meta_fetch(0);
-      meta_store();
-      fetch(0);
-    }
-    __syncthreads();
-    if (!loader) {
-#pragma unroll
-      for (int v = 0; v < 3; ++v) { round_issue(0, 0, v); round_take(v); }
-    }
-    f16v acc;
-    for (int s = 0; s < n_stage; ++s) {
-      const int pos = s / KH, kh = s - pos * KH;
-      const int sn = s + 1, posn = sn / KH, khn = sn - posn * KH;   // the stage being prepared by the builders
-      if (kh == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-      }
-      __syncthreads();  // the previous stage has been consumed
-      if (loader) {
-        float *dst = As + srow * GQ_ROW + sc4 * 4;
-#pragma unroll
-        for (int k = 0; k < NRA; ++k) *(f4 *)&dst[((k >> 2) * 32 + 8 * (k & 3)) * GQ_ROW] = st[k];
-        if (kh == 0 && tid < JT * 32) cls[tid] = clv;
-        // the records of the group the NEXT listed pixel belongs to, when it opens a group (fetched one stage earlier)
-        if (khn == 0 && posn < npl && posn % MP == 0) meta_store();
-      } else {
-        float *dst = Bs + srow * GQ_ROW + sc4 * 4;
-#pragma unroll
-        for (int k = 0; k < NRB; ++k) *(f4 *)&dst[((k >> 2) * 32 + 8 * (k & 3)) * GQ_ROW] = st[k];
-      }
-      __syncthreads();
-      const bool more = sn < n_stage;
-      if (loader) {
-        if (more) fetch(sn);
-        // records two listed pixels ahead: they are stored one stage before the builders read them
-        const int s2 = s + 2, pos2 = s2 / KH;
-        if (s2 < n_stage && s2 - pos2 * KH == 0 && pos2 % MP == 0) meta_fetch(pos2 / MP);
-      }
-      // does any of this wave's 32 poses cover the pixel?  (wave-uniform)
-      const bool live = !(NEMO_GR_ABL & 2) && __builtin_amdgcn_ballot_w64(bcov[(pos & 1) * PR + pt * 32 + i] != 0) != 0ull;
-      const float *ap = As + (jt * 32 + i) * GQ_ROW + 4 * half, *bp = Bs + (pt * 32 + i) * GQ_ROW + 4 * half;
-      // one 16-byte operand step = 4 of the stage's 64 matrix instructions; the operands of the next step are read from
-      // LDS before this step's instructions are issued (two waves per SIMD do not hide that latency by themselves)
-      f4 a_cur = f4{0.f, 0.f, 0.f, 0.f}, b_cur = a_cur;
-      if (live) { a_cur = *(const f4 *)ap; b_cur = *(const f4 *)bp; }
-      auto mfma_group = [&](int q) {
-        if (live) {
-          const f4 a = a_cur, b = b_cur;
-          if (q + 1 < 16) { a_cur = *(const f4 *)(ap + 8 * (q + 1)); b_cur = *(const f4 *)(bp + 8 * (q + 1)); }
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
-        }
+  __syncthreads();
+  for (int tg = 0; tg < ns; tg += JT * 32) {
+    if (matrix) {
+      // records are staged MP listed pixels at a time: matrix thread t owns item t = (pose row t / MP, list slot t % MP)
+      typedef float f3v __attribute__((ext_vector_type(3), aligned(4)));
+      RecVid mvr;
+      f3v mbr;
+      const int mpxs = tid % MP, mlds = mpxs * PR + tid / MP;
+      const size_t mbase = ((size_t)sl * G + min(g0 + tid / MP, G - 1)) * hw + p0;  // (the item's pose, pixel 0 of the chunk)
+      auto meta_fetch = [&](int grp) {
+        const size_t idx = mbase + plist[min(grp * MP + mpxs, npl - 1)];
+        mvr = vid[idx];
+        mbr = *(const f3v *)(bary + 3 * idx);
       };
-      const bool build = !loader && more;
-      // three rounds between the sixteen operand steps
+      auto meta_store = [&](int grp) {
+        const int o = (grp & 1) * MP * PR + mlds;
+        mv01[o] = mvr.v01; mv2c[o] = mvr.v2c;
+        mb[o * 3] = mbr.x; mb[o * 3 + 1] = mbr.y; mb[o * 3 + 2] = mbr.z;
+      };
+      f16v lsum;
 #pragma unroll
-      for (int v = 0; v < 3; ++v) {
-        if (build) round_issue(posn, khn, v);
-        __builtin_amdgcn_sched_barrier(0);
+      for (int r = 0; r < 16; ++r) lsum[r] = 0.0f;
+      // ---- prologue: the records of the first group
+      meta_fetch(0);
+      meta_store(0);
+      __syncthreads();   // the staging waves read the records
+      __syncthreads();   // ... and have written the rows of stage 0
+      f16v acc;
+      for (int s = 0; s < n_stage; ++s) {
+        const int pos = s / NKS, ks = s - pos * NKS;
+        if (ks == 0) {
 #pragma unroll
-        for (int q = 5 * v; q < 5 * v + 5; ++q) mfma_group(q);
-        __builtin_amdgcn_sched_barrier(0);
-        if (build) round_take(v);
-      }
-      mfma_group(15);
-      // C/D layout: column = lane & 31 (pose), row = (r & 3) + 8 * (r >> 2) + 4 * half (job of the tile)
-      if (kh == KH - 1 && live) {
+          for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        }
+        // does any of this wave's 32 poses cover the pixel?  (wave-uniform; a dead tile contributes nothing)
+        // So does a job tile beyond the end of a ragged pass.
+        const bool live = !(NEMO_GR_ABL & 2) && tg + jt * 32 < ns &&
+                          __builtin_amdgcn_ballot_w64(bcov[(pos & 1) * PR + pt * 32 + i] != 0) != 0ull;
+        // records: fetched four stages, stored two stages before the staging waves first read the group
+        if ((s + 2) % GS == 0 && s + 2 < n_stage) meta_store((s + 2) / GS);
+        if ((s + 4) % GS == 0 && s + 4 < n_stage) meta_fetch((s + 4) / GS);
+        if (live) {
+          const float *ap = gq_sm + (s & 1) * GR_BUF + (jt * 32 + i) * ROW + 4 * half;
+          const float *bp = gq_sm + (s & 1) * GR_BUF + ((JT + pt) * 32 + i) * ROW + 4 * half;
+          // one 16-byte operand step = 4 of the stage's 32 matrix instructions; the operands of the next step are read
+          // from LDS before this step's instructions are issued
+          f4 a0 = *(const f4 *)ap, bb = *(const f4 *)bp;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const f4 cv = *(const f4 *)&cls[jt * 32 + 8 * k + 4 * half];
-          const float cc[4] = {cv.x, cv.y, cv.z, cv.w};
+          for (int q = 0; q < GR_KS / 8; ++q) {
+            const f4 x0 = a0, y = bb;
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 1 < GR_KS / 8) { a0 = *(const f4 *)(ap + 8 * (q + 1)); bb = *(const f4 *)(bp + 8 * (q + 1)); }
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.x, y.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, y.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.z, y.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.w, y.w, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          // C/D layout: column = lane & 31 (pose), row = (r & 3) + 8 * (r >> 2) + 4 * half (job of the tile)
+          if (ks == NKS - 1) {
+            const float *cl_ = cls + (pos & 1) * JT * 32 + jt * 32 + 4 * half;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float o = acc[4 * k + r];
-            lsum[4 * k + r] += clutter_on ? (fmaxf(o, cc[r]) - fmaxf(0.0f, cc[r])) : o;
+            for (int k = 0; k < 4; ++k) {
+              const f4 cv = *(const f4 *)&cl_[8 * k];
+              const float cc[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float o = acc[4 * k + r];
+                lsum[4 * k + r] += clutter_on ? (fmaxf(o, cc[r]) - fmaxf(0.0f, cc[r])) : o;
+              }
+            }
           }
         }
+        __syncthreads();  // stage s has been consumed, stage s + 1 is in place
       }
-    }
-    {
       const int g = g0 + pt * 32 + i;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int jrow = tg + jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (jrow < ns && g < G) partial[((size_t)c * N + order[js + jrow]) * G + g] = lsum[r];
+        const int jr = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (tg + jr < ns && g < G) partial[((size_t)c * N + ordl[jr]) * G + g] = lsum[r];
+      }
+    } else {
+      // ---- per-pass offsets (in 16-byte units: the feature tensor may exceed 4 GiB, its 16-byte index does not)
+      uint32_t ro[NRA];   // feature rows of the pass's jobs at pixel 0 of the chunk
+#pragma unroll
+      for (int k = 0; k < NRA; ++k) {
+        const int job = order[js + min(tg + srow + 32 * k, ns - 1)];
+        ro[k] = (uint32_t)((((size_t)(img_idx ? img_idx[job] : job) * hw + p0) * D) >> 2) + (uint32_t)sc4;
+      }
+      // the clutter score of job t2 at the stage's pixel (threads that stage none read a valid dummy: the load below is
+      // unconditional so that the memory counter's arithmetic is exact)
+      const bool has_cl = clutter_on && t2 < JT * 32;
+      const float *clp = feat;
+      if (has_cl) {
+        const int job = order[js + min(tg + t2, ns - 1)];
+        clp = clu + (size_t)(img_idx ? img_idx[job] : job) * hw + p0;
+      }
+      f4 st[NRA];   // the feature-row fragments of the stage after next travel through registers
+      float clv = 0.0f;
+      auto fetch = [&](int s) {
+        const int px = plist[s / NKS], ks = s % NKS;
+#pragma unroll
+        for (int k = 0; k < NRA; ++k)
+          st[k] = (NEMO_GR_ABL & 8) ? f4{0.f, 0.f, 0.f, 0.f} : feat4[ro[k] + (uint32_t)(px * (D / 4) + ks * (GR_KS / 4))];
+        clv = (NEMO_GR_ABL & 8) ? 0.f : clp[has_cl ? px : 0];
+      };
+      auto put_rows = [&](int s) {   // the fetched fragments of stage s go to its buffer
+        float *dst = gq_sm + (s & 1) * GR_BUF + srow * ROW + sc4 * 4;
+#pragma unroll
+        for (int k = 0; k < NRA; ++k) *(f4 *)&dst[32 * k * ROW] = st[k];
+        if (s % NKS == 0 && has_cl) cls[((s / NKS) & 1) * JT * 32 + t2] = clv;
+      };
+      // the NRB pose-row fragments of the next stage = three bank rows each, weighted by the barycentrics
+      f4 m[3][NRB];
+      float bw[3][NRB];
+      auto build_issue = [&](int s) {
+        const int pos = s / NKS, ks = s - pos * NKS;
+        // one variable LDS index per stage; fragment k's row is a compile-time distance from it
+        const int base = ((pos / MP) & 1) * MP * PR + (pos % MP) * PR + srow;
+        const uint32_t *a_ = mv01 + base, *b_ = mv2c + base;
+        const float *w_ = mb + 3 * base;
+        int *c_ = bcov + (pos & 1) * PR + srow;
+        const uint32_t col = (uint32_t)(ks * GR_KS + sc4 * 4);
+        uint32_t ra[NRB], rb[NRB];
+#pragma unroll
+        for (int k = 0; k < NRB; ++k) {   // every LDS read of the stage first ...
+          ra[k] = a_[32 * k]; rb[k] = b_[32 * k];
+#pragma unroll
+          for (int v = 0; v < 3; ++v) bw[v][k] = w_[3 * 32 * k + v];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < NRB; ++k) {   // ... then the 3 NRB bank-row loads, none of them conditional: a row that does not
+          const bool cov = (rb[k] >> 16) != 0u;   // cover the pixel reads bank row 0 with zero weights (records hold 0, 0, 0)
+          const uint32_t vv[3] = {ra[k] & 0xffffu, ra[k] >> 16, rb[k] & 0xffffu};
+#pragma unroll
+          for (int v = 0; v < 3; ++v) {
+            m[v][k] = (NEMO_GR_ABL & 1) ? f4{0.f, 0.f, 0.f, 0.f} : *(gf4p)(bank + (vv[v] * (uint32_t)D + col));
+          }
+          if (ks == 0 && sc4 == 0) c_[32 * k] = cov ? 1 : 0;
+        }
+      };
+      auto build_put = [&](int s) {
+        float *dst = gq_sm + (s & 1) * GR_BUF + (JT * 32 + srow) * ROW + sc4 * 4;
+#pragma unroll
+        for (int k = 0; k < NRB; ++k)   // (b0 * r0 + b1 * r1) + b2 * r2: interpolate_kernel's arithmetic
+          *(f4 *)&dst[32 * k * ROW] = (bw[0][k] * m[0][k] + bw[1][k] * m[1][k]) + bw[2][k] * m[2][k];
+      };
+      // ---- prologue: the job ids of the pass, the feature rows of stages 0 and 1, the pose rows of stage 0
+      if (t2 < JT * 32) ordl[t2] = order[js + min(tg + t2, ns - 1)];
+      fetch(0);
+      put_rows(0);
+      fetch(min(1, n_stage - 1));
+      __syncthreads();   // the records of the first group are in LDS
+      build_issue(0);
+      build_put(0);
+      __syncthreads();
+      for (int s = 0; s < n_stage; ++s) {
+        if (s + 1 < n_stage && !(NEMO_GR_ABL & 4)) {
+          build_issue(s + 1);                    // 3 NRB loads (L2)
+          __builtin_amdgcn_sched_barrier(0);
+          put_rows(s + 1);                       // the NRA + 1 loads issued one stage ago
+          __builtin_amdgcn_sched_barrier(0);
+          fetch(min(s + 2, n_stage - 1));        // NRA + 1 loads (HBM), younger than the bank rows build_put waits for
+          __builtin_amdgcn_sched_barrier(0);
+          build_put(s + 1);
+        }
+        __syncthreads();
       }
     }
     __syncthreads();  // the next pass restages the LDS

@@ -82,7 +82,7 @@ struct nemo_ctx {
   int n_cu;              // its compute-unit count (cached: hipGetDeviceProperties is slow)
   // environment switches, read ONCE in nemo_ctx_create (hot calls never call getenv)
   int env_grid_no_mfma, env_solve_stagger, env_solve_order, env_solve_affinity, env_slot_identity;
-  int env_grid_rec_min;  // NEMO_GRID_REC_MIN_POSES: grids with at least this many poses use the record store (0: never)
+  int env_grid_records;  // NEMO_GRID_RECORDS: -1 (default) the record store when the dense renders do not fit; 0 never; 1 whenever it fits
   double env_prerender_map_gb;
   char err[512];
 };
@@ -339,7 +339,7 @@ int nemo_ctx_create(const nemo_config *cfg, nemo_ctx **out) {
   ctx->env_solve_order = env_int("NEMO_SOLVE_ORDER", 1);
   ctx->env_solve_affinity = env_int("NEMO_SOLVE_AFFINITY", 1);
   ctx->env_slot_identity = env_int("NEMO_SLOT_ORDER", 1) == 0;
-  ctx->env_grid_rec_min = env_int("NEMO_GRID_REC_MIN_POSES", 512);
+  ctx->env_grid_records = env_int("NEMO_GRID_RECORDS", -1);
   {
     const char *v = getenv("NEMO_PRERENDER_MAP_GB");
     ctx->env_prerender_map_gb = v ? atof(v) : 48.0;
@@ -708,8 +708,13 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
   // Record store (dense grids): per (pair, pose, pixel) three vertex ids + covered flag and three barycentrics, 20 bytes,
   // from which grid_mfma_rec_kernel builds the rendered rows on the fly.  Rendered here in slices of poses through a
   // temporary pix_to_face / bary buffer (campos -> rasterize -> pack).  Ordinary (LDS-table) meshes only.
-  if (n_pairs <= GP_MAX_PAIRS && !ctx->P.big && !ctx->env_grid_no_mfma && ctx->env_grid_rec_min > 0 && G >= ctx->env_grid_rec_min &&
-      (double)n_pairs * G * stride * 20.0 <= ctx->env_prerender_map_gb * 1073741824.0) {
+  // Chosen when the dense renders of all G poses exceed the budget and the records do not (measured, BASELINE config 4:
+  // 12 classes x 9720 poses, 0.277 s against 0.455 s for block-after-block rendering; when the renders fit they are
+  // the faster operand, 0.197 s against 0.227 s for one class -- profiles/r03_dense_grid_records.md).
+  const double map_budget = ctx->env_prerender_map_gb * 1073741824.0;
+  const bool maps_fit = (double)n_pairs * G * stride * ctx->cfg.feat_dim * 4.0 <= map_budget;
+  if (n_pairs <= GP_MAX_PAIRS && !ctx->P.big && !ctx->env_grid_no_mfma && (double)n_pairs * G * stride * 20.0 <= map_budget &&
+      (ctx->env_grid_records > 0 || (ctx->env_grid_records < 0 && !maps_fit))) {
     const size_t n_rec = (size_t)n_pairs * G * stride;
     const int n_chunks = (int)((stride + GP_PIX - 1) / GP_PIX);
     long gb = (long)((2048.0 * 1048576.0) / ((double)n_pairs * stride * 16.0));   // about 2 GiB of scratch per slice
@@ -760,7 +765,7 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
     }
     return NEMO_OK;
   }
-  if (n_pairs <= GP_MAX_PAIRS) {
+  if (n_pairs <= GP_MAX_PAIRS && !ctx->env_grid_no_mfma) {
     const double budget = ctx->env_prerender_map_gb * 1073741824.0;
     const size_t D = (size_t)ctx->cfg.feat_dim;
     const double per_pose = (double)n_pairs * stride * D * 4.0;  // one pose of every pair
@@ -801,6 +806,13 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
     }
   }
   return NEMO_OK;
+}
+
+int nemo_grid_store_kind(const nemo_ctx *ctx) {
+  if (!ctx) return 0;
+  if (ctx->d_pre_vid) return 3;
+  if (ctx->d_pre_maps) return ctx->pre_block == ctx->pre_G ? 1 : 2;
+  return 0;
 }
 
 // Shared by nemo_solve / nemo_solve6 / nemo_solve_static: launch order (longest job first), then the fused solve.

@@ -307,6 +307,12 @@ class PoseEngine:
                    'nemo_grid_prerender')
         self._pre_keep = (grid_C, grid_theta)  # the store is keyed by these device buffers: keep them alive
 
+    GRID_STORE_KINDS = ('none', 'dense_maps', 'pose_blocks', 'records')
+
+    def grid_store_kind(self):
+        """Which operand of the matrix-core grid search the context holds (nemo_grid_store_kind)."""
+        return self.GRID_STORE_KINDS[self.lib.nemo_grid_store_kind(self.ctx)]
+
     def solve(self, feat, clu, C0, theta0, img_idx=None, mesh_idx=None, want_trace=False, out=None, static=False,
               status=None):
         """nemo_solve.  `out` = (pose [N,4], loss [N]) buffers to fill instead of fresh ones; static=True goes

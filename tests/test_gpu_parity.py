@@ -1282,23 +1282,34 @@ def test_dense_grid_tiled_over_pose_blocks(oracle, monkeypatch):
     feats, clus = _dev(np.concatenate([a.feats, b.feats])), _dev(np.concatenate([a.clus, b.clus]))
     mesh = _dev([0, 0, 1, 1], torch.int32)
     out = {}
-    for mode, gb in (('tiled', '0.15'), ('resident', '48'), ('records', '48')):
+    kinds = {'tiled': 'pose_blocks', 'resident': 'dense_maps', 'records': 'records', 'auto': 'records'}
+    for mode, gb in (('tiled', '0.15'), ('resident', '48'), ('records', '48'), ('auto', '0.15')):
         monkeypatch.setenv('NEMO_PRERENDER_MAP_GB', gb)       # read once, at context creation
-        # 'records': no dense maps at all -- the pose operand is built from the 20-byte record store (dense grids take
-        # this path from 512 poses on; forced here)
-        monkeypatch.setenv('NEMO_GRID_REC_MIN_POSES', '1' if mode == 'records' else '0')
+        # 'records': no dense maps at all -- the pose operand is built from the 20-byte record store.  By default ('auto')
+        # the store is chosen when the dense renders exceed the budget and the records do not; '1' prefers it, '0' bars it
+        if mode == 'auto':
+            monkeypatch.delenv('NEMO_GRID_RECORDS', raising=False)
+        else:
+            monkeypatch.setenv('NEMO_GRID_RECORDS', '1' if mode == 'records' else '0')
         eng = PoseEngine(a.geo.S, (a.geo.h, a.geo.w), a.D)
         eng.register_mesh(a.verts, a.faces, a.bank)
         eng.register_mesh(b.verts, b.faces, b.bank)
+        assert eng.grid_store_kind() == 'none'
         eng.grid_prerender(dC, dth, [(0, 0), (1, 1)])
-        free0 = torch.cuda.mem_get_info()[0]
+        assert eng.grid_store_kind() == kinds[mode]
+        # the first call of a process may make the HIP runtime load code objects and size its per-queue scratch; after
+        # it, a search allocates nothing (torch's outputs aside) -- block rendering included
         out[mode] = eng.grid_search(feats, clus, dC, dth, mesh_idx=mesh, grid_idx=mesh)
-        eng.grid_search(feats, clus, dC, dth, mesh_idx=mesh, grid_idx=mesh, losses=out[mode][3].clone())
         torch.cuda.synchronize()
-        assert torch.cuda.mem_get_info()[0] >= free0 - (8 << 20)          # block rendering allocates nothing (torch outputs aside)
+        free0 = torch.cuda.mem_get_info()[0]
+        again = eng.grid_search(feats, clus, dC, dth, mesh_idx=mesh, grid_idx=mesh, losses=out[mode][3].clone())
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info()[0] >= free0 - (8 << 20)
+        assert torch.equal(again[3], out[mode][3])
     # 2 pairs x 1536 px x 128 x 4 B = 1.5 MB per pose: 0.15 GB hold 102 -> 96 poses per block, 288 poses = 3 blocks
     assert torch.equal(out['tiled'][3], out['resident'][3]) and torch.equal(out['tiled'][2], out['resident'][2])
     assert torch.equal(out['records'][3], out['resident'][3]) and torch.equal(out['records'][2], out['resident'][2])
+    assert torch.equal(out['auto'][3], out['resident'][3]) and torch.equal(out['auto'][2], out['resident'][2])
     best, losses = out['tiled'][2].cpu().numpy(), out['tiled'][3].cpu().numpy()
     for k in range(4):
         sc, (gC, gth) = ((a, grids[0]) if k < 2 else (b, grids[1]))
@@ -1312,7 +1323,7 @@ def test_dense_grid_record_store(oracle, monkeypatch, D, clutter):
     """The record-based matrix-core grid search (no materialised renders) on its own: 256-d features (two feature
     halves per pixel) and the loss without clutter, more jobs than one 64-job pass, a window whose last pixel chunk
     is partial, against the oracle."""
-    monkeypatch.setenv('NEMO_GRID_REC_MIN_POSES', '1')
+    monkeypatch.setenv('NEMO_GRID_RECORDS', '1')
     sc = make_scene(image_hw=(136, 200), number_vertices=150, n_img=3, seed=43, D=D, clutter=clutter)
     assert (sc.cfg.h * sc.cfg.w) % 64 != 0
     eng = _engine(sc)

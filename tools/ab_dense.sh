@@ -5,5 +5,5 @@ for sfx in "$@"; do
   [ "$sfx" = "-" ] && sfx=""
   echo "== ${sfx:-shipped}"
   if [ -n "$sfx" ]; then export NEMO_HIP_LIB=$GRAFT_REPO_ROOT/nemo_amd/lib/libnemo_hip$sfx.so; else unset NEMO_HIP_LIB; fi
-  timeout -k 10 200 python tools/bench_configs.py ${MODE:-dense} 2>&1 | grep -o '"seconds": [0-9.]*' | head -2 || exit 1
+  timeout -k 10 200 python tools/bench_configs.py ${MODE:-dense} 2>&1 | grep -o '"seconds": [0-9.]*' | head -3 || exit 1
 done

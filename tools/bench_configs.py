@@ -68,59 +68,89 @@ def multi(n_images=1024, seed=3):
             'seconds': dt, 'images_per_s': n_images / dt, 'job_solves_per_s': len(img) / dt, 'generating_subtype_wins': hit}
 
 
+_ENV = ('NEMO_PRERENDER_MAP_GB', 'NEMO_GRID_NO_MFMA', 'NEMO_GRID_RECORDS')
+
+
+class _env:
+    """Environment switches for one context (they are read at nemo_ctx_create) -- put back afterwards, or the
+    configurations that follow in this process inherit them (round 2's "0.835 s against 0.652 s" for `big`,
+    profiles/r03_cfg5_discrepancy.md)."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.saved = {k: os.environ.get(k) for k in _ENV}
+        for k in _ENV:
+            os.environ.pop(k, None)
+        os.environ.update({k: str(v) for k, v in self.kv.items()})
+
+    def __exit__(self, *exc):
+        for k, v in self.saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def dense(n_images=1024, seed=4):
-    """configs[3]: 36 azimuth x 9 elevation x 6 theta x 5 distance = 9720 grid poses per image, one class."""
-    rng = np.random.default_rng(seed)
-    cfg = SolverConfig()
-    s = BatchPoseSolver(cfg)
-    d = syn.DISTANCE_RENDER['car']
-    v, f = syn.class_mesh('car', 1000)
-    s.add_mesh(v, f, syn.unit_rows(rng, len(v), cfg.feat_dim), d)
-    gC, gth = syn.pose_grid(d, n_azim=36, n_elev=9, n_theta=6, distances=tuple(d * x for x in (0.8, 0.9, 1.0, 1.1, 1.2)))
-    dC, dth = torch.as_tensor(gC[None]).cuda().contiguous(), torch.as_tensor(gth[None]).cuda().contiguous()
-    mesh_idx = torch.zeros(n_images, dtype=torch.int32, device='cuda')
-    feats = _render_features(s, mesh_idx, gt_poses(rng, ['car'] * n_images), rng, 0.5)
-    eng = s.engine
-    clu = eng.clutter_score(feats, s.clutter_vector(torch.as_tensor(syn.unit_rows(rng, 64, cfg.feat_dim)).cuda()))
-    os.environ.setdefault('NEMO_PRERENDER_MAP_GB', '64')
-    t0 = time.perf_counter()
-    eng.grid_prerender(dC, dth, [(0, 0)])
-    torch.cuda.synchronize()
-    t_pre = time.perf_counter() - t0
-    dt, _ = timed(lambda: eng.grid_search(feats, clu, dC, dth, mesh_idx=mesh_idx, grid_idx=mesh_idx))
-    G = len(gth)
-    eng.counter_reset()
-    eng.grid_search(feats, clu, dC, dth, mesh_idx=mesh_idx, grid_idx=mesh_idx)
-    cov = eng.counter_read()                                  # covered (pixel, pose, image) triples of one search
-    return {'config': 'dense pose grid, one class', 'images': n_images, 'poses_per_image': G, 'prerender_seconds': t_pre,
-            'seconds': dt, 'pose_evaluations_per_s': n_images * G / dt,
-            'window_TFLOPs': 2.0 * cfg.feat_dim * G * n_images * eng.h * eng.w / dt / 1e12,
-            'useful_TFLOPs_covered_pixels_only': 2.0 * cfg.feat_dim * cov / dt / 1e12}
+    """configs[3]: 36 azimuth x 9 elevation x 6 theta x 5 distance = 9720 grid poses per image, one class.  The default
+    operand of the matrix-core contraction (the 40 GB of dense renders fit) and, for comparison, the record store."""
+    out = {}
+    for mode, env in (('default', {}), ('records', {'NEMO_GRID_RECORDS': 1})):
+        with _env(**env):
+            rng = np.random.default_rng(seed)
+            cfg = SolverConfig()
+            s = BatchPoseSolver(cfg)
+            d = syn.DISTANCE_RENDER['car']
+            v, f = syn.class_mesh('car', 1000)
+            s.add_mesh(v, f, syn.unit_rows(rng, len(v), cfg.feat_dim), d)
+            gC, gth = syn.pose_grid(d, n_azim=36, n_elev=9, n_theta=6, distances=tuple(d * x for x in (0.8, 0.9, 1.0, 1.1, 1.2)))
+            dC, dth = torch.as_tensor(gC[None]).cuda().contiguous(), torch.as_tensor(gth[None]).cuda().contiguous()
+            mesh_idx = torch.zeros(n_images, dtype=torch.int32, device='cuda')
+            feats = _render_features(s, mesh_idx, gt_poses(rng, ['car'] * n_images), rng, 0.5)
+            eng = s.engine
+        clu = eng.clutter_score(feats, s.clutter_vector(torch.as_tensor(syn.unit_rows(rng, 64, cfg.feat_dim)).cuda()))
+        t0 = time.perf_counter()
+        eng.grid_prerender(dC, dth, [(0, 0)])
+        torch.cuda.synchronize()
+        t_pre = time.perf_counter() - t0
+        dt, res = timed(lambda: eng.grid_search(feats, clu, dC, dth, mesh_idx=mesh_idx, grid_idx=mesh_idx))
+        G = len(gth)
+        eng.counter_reset()
+        eng.grid_search(feats, clu, dC, dth, mesh_idx=mesh_idx, grid_idx=mesh_idx)
+        cov = eng.counter_read()                                  # covered (pixel, pose, image) triples of one search
+        out[mode] = {'store': eng.grid_store_kind(), 'images': n_images, 'poses_per_image': G, 'prerender_seconds': t_pre,
+                     'seconds': dt, 'pose_evaluations_per_s': n_images * G / dt,
+                     'window_TFLOPs': 2.0 * cfg.feat_dim * G * n_images * eng.h * eng.w / dt / 1e12,
+                     'useful_TFLOPs_covered_pixels_only': 2.0 * cfg.feat_dim * cov / dt / 1e12, 'best': res[2][:8].tolist()}
+        del s, eng, feats, clu
+        torch.cuda.empty_cache()
+    out['same_argmin_on_the_first_images'] = out['default']['best'] == out['records']['best']
+    return {'config': 'dense pose grid, one class', **out}
 
 
 def dense12(n_images=1024, seed=4):
-    """configs[3] on the 12-class workload: 9720 poses x 12 meshes of dense renders (478 GB) do not fit, so the grid
-    search renders pose blocks into the NEMO_PRERENDER_MAP_GB buffer and contracts them on the matrix cores block by
-    block.  Also timed: the list path (no dense maps) the same search used to fall back to."""
+    """configs[3] on the 12-class workload: 9720 poses x 12 meshes of dense renders (478 GB) do not fit.  Default: the
+    19 GB record store, rows built on the fly.  Also timed: block-after-block rendering into the map buffer
+    (NEMO_GRID_RECORDS=0, round 2's path) and the list path (no matrix cores)."""
     cfg = SolverConfig()
     out = {}
-    saved = {k: os.environ.get(k) for k in ('NEMO_PRERENDER_MAP_GB', 'NEMO_GRID_NO_MFMA')}
-    for mode in ('tiled_matrix_core', 'list_path'):
-        os.environ['NEMO_PRERENDER_MAP_GB'] = '48'
-        os.environ['NEMO_GRID_NO_MFMA'] = '1' if mode == 'list_path' else '0'
-        s = BatchPoseSolver(cfg)
-        gCs, gts = [], []
-        for c in syn.CATEGORIES:
-            v, f = syn.class_mesh(c, 1000)
-            d = syn.DISTANCE_RENDER[c]
-            s.add_mesh(v, f, syn.unit_rows(np.random.default_rng(seed + 1), len(v), cfg.feat_dim), d)
-            gC, gth = syn.pose_grid(d, n_azim=36, n_elev=9, n_theta=6, distances=tuple(d * x for x in (0.8, 0.9, 1.0, 1.1, 1.2)))
-            gCs.append(gC); gts.append(gth)
-        dC, dth = torch.as_tensor(np.stack(gCs)).cuda().contiguous(), torch.as_tensor(np.stack(gts)).cuda().contiguous()
-        cats = [syn.CATEGORIES[i % 12] for i in range(n_images)]
-        mesh_idx = torch.as_tensor((np.arange(n_images) % 12).astype(np.int32)).cuda()
-        feats = _render_features(s, mesh_idx, gt_poses(np.random.default_rng(seed + 2), cats), np.random.default_rng(seed + 3), 0.5)
-        eng = s.engine
+    for mode, env in (('default', {}), ('pose_blocks', {'NEMO_GRID_RECORDS': 0}), ('list_path', {'NEMO_GRID_NO_MFMA': 1})):
+        with _env(**env):
+            s = BatchPoseSolver(cfg)
+            gCs, gts = [], []
+            for c in syn.CATEGORIES:
+                v, f = syn.class_mesh(c, 1000)
+                d = syn.DISTANCE_RENDER[c]
+                s.add_mesh(v, f, syn.unit_rows(np.random.default_rng(seed + 1), len(v), cfg.feat_dim), d)
+                gC, gth = syn.pose_grid(d, n_azim=36, n_elev=9, n_theta=6, distances=tuple(d * x for x in (0.8, 0.9, 1.0, 1.1, 1.2)))
+                gCs.append(gC); gts.append(gth)
+            dC, dth = torch.as_tensor(np.stack(gCs)).cuda().contiguous(), torch.as_tensor(np.stack(gts)).cuda().contiguous()
+            cats = [syn.CATEGORIES[i % 12] for i in range(n_images)]
+            mesh_idx = torch.as_tensor((np.arange(n_images) % 12).astype(np.int32)).cuda()
+            feats = _render_features(s, mesh_idx, gt_poses(np.random.default_rng(seed + 2), cats), np.random.default_rng(seed + 3), 0.5)
+            eng = s.engine
         clu = eng.clutter_score(feats, s.clutter_vector(torch.as_tensor(syn.unit_rows(np.random.default_rng(seed + 4), 64, cfg.feat_dim)).cuda()))
         G = dth.shape[1]
         eng.reserve(n_images, G)
@@ -134,19 +164,12 @@ def dense12(n_images=1024, seed=4):
                                       grid_idx=mesh_idx[:n].contiguous())
         dt, res = timed(run, reps=1)
         eng.counter_reset(); run(); cov = eng.counter_read()
-        out[mode] = {'images': n, 'poses_per_image': G, 'prerender_seconds': t_pre, 'seconds': dt,
+        out[mode] = {'store': eng.grid_store_kind(), 'images': n, 'poses_per_image': G, 'prerender_seconds': t_pre, 'seconds': dt,
                      'pose_evaluations_per_s': n * G / dt, 'useful_TFLOPs_covered_pixels_only': 2.0 * cfg.feat_dim * cov / dt / 1e12,
                      'best': res[2][:8].tolist()}
         del s, eng, feats, clu
         torch.cuda.empty_cache()
-    # the switches are read at nemo_ctx_create: put them back, or the configurations that follow in this process
-    # run their grid search on the list path (round 2's "0.835 s against 0.652 s" for `big`, profiles/r03_cfg5_discrepancy.md)
-    for k, v in saved.items():
-        if v is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = v
-    out['same_argmin_on_the_first_images'] = out['tiled_matrix_core']['best'] == out['list_path']['best']
+    out['same_argmin_on_the_first_images'] = out['default']['best'] == out['pose_blocks']['best'] == out['list_path']['best']
     return {'config': 'dense pose grid, 12 classes (9720 poses x 12 meshes)', **out}
 
 
