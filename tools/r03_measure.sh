@@ -18,6 +18,10 @@ for step in "$@"; do
     pmc)      for c in FETCH_SIZE WRITE_SIZE; do
                 timeout -s KILL 150 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 tools/prof_solve.py --images 1024 --steps 300 --reps 1 --grid > $O/pmc_$c.log 2>&1 || exit 1
               done ;;
+    pmc_dense12) for c in FETCH_SIZE WRITE_SIZE; do
+                timeout -s KILL 200 rocprofv3 --pmc $c --output-format csv -d $O/pmcd12_$c -- python3 tools/bench_configs.py dense12 > $O/pmcd12_$c.log 2>&1 || exit 1
+              done
+              python3 tools/pmc_kernels.py $O/pmcd12_FETCH_SIZE $O/pmcd12_WRITE_SIZE $O/pmc_dense12.json "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/bench_configs.py dense12" || exit 1 ;;
     clutter)  prof clutter 200 tools/time_clutter.py || exit 1 ;;
     head)     prof head 200 tools/prof_head.py || exit 1 ;;
     multi|dense|dense12|big)
