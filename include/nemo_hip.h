@@ -159,13 +159,16 @@ int nemo_grid_search(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const i
  * What is kept (all three give the same losses; the matrix-core forms bit for bit the same as each other):
  *   - always: per (pair, pose) the list of covered pixels with their faces, n_pairs*G*win_h*win_w*4 bytes;
  *   - the operand of the matrix-core grid search, within NEMO_PRERENDER_MAP_GB (default 48) of device memory:
- *     1 the dense renders f32[pair][G][win_h*win_w][D] when they fit, rendered here once;
+ *     1 the dense renders f32[pair][G][win_h*win_w][D] when they fit and G < 4096, rendered here once;
  *     3 else, for meshes whose tables fit the LDS, a record per (pair, pose, pixel) -- three 16-bit vertex ids, a covered
  *       flag, three barycentrics, 20 bytes -- from which nemo_grid_search builds the rendered rows on the fly in LDS
- *       (BASELINE config 4, 12 classes x 9720 poses: 19 GB of records instead of 478 GB of renders);
+ *       (BASELINE config 4, 12 classes x 9720 poses: 19 GB of records instead of 478 GB of renders).  The store keeps
+ *       poses with alike silhouettes next to each other (tiles of 32 poses whose pixels nobody covers are skipped);
+ *       losses are reported in grid order and do not depend on the store's order;
  *     2 else a buffer for a block of poses (a multiple of 32) that nemo_grid_search re-renders block after block.
  *   NEMO_GRID_RECORDS=1 in the environment (at nemo_ctx_create) prefers 3 whenever the records fit, =0 never uses it;
- *   NEMO_GRID_NO_MFMA=1 keeps the list path only.  nemo_grid_store_kind reports which form the context holds. */
+ *   NEMO_GRID_GROUP=0 keeps the record store in grid order; NEMO_GRID_NO_MFMA=1 keeps the list path only.
+ *   nemo_grid_store_kind reports which form the context holds. */
 int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_grid_theta, int32_t n_grids,
                         int32_t G, const int32_t *h_pair_mesh, const int32_t *h_pair_grid, int32_t n_pairs,
                         void *stream);

@@ -223,12 +223,12 @@ __global__ __launch_bounds__(1024) void grid_mfma_lds_kernel(int hw, int N, int 
 // pack_rec_kernel turns the rasteriser's (pix_to_face, bary) of a block of poses into the records.
 struct RecVid { uint32_t v01, v2c; };  // v0 | v1 << 16, v2 | covered << 16
 __global__ void pack_rec_kernel(size_t npix, size_t hw, int G, int g0, int gb, const MeshDesc *meshes, const int32_t *mesh_of_job,
-                                const int32_t *p2f, const float *bary, RecVid *vid, float *bout) {
+                                const int32_t *p2f, const float *bary, const int32_t *slot_of, RecVid *vid, float *bout) {
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // (job = pair * gb + b, pixel)
   if (k >= npix) return;
   const size_t job = k / hw, pix = k - job * hw;
   const size_t pair = job / gb, b = job - pair * gb;
-  const size_t dst = (pair * G + g0 + b) * hw + pix;
+  const size_t dst = (pair * G + (size_t)slot_of[pair * G + g0 + b]) * hw + pix;   // the store is in slot order (rec_group_kernel)
   const int f = p2f[k];
   RecVid r{0u, 0u};
   float b0 = 0.f, b1 = 0.f, b2 = 0.f;
@@ -252,6 +252,123 @@ constexpr int GR_ROW = GR_KS + 4;  // padded LDS row: the 16-byte operand reads 
 constexpr int GR_BUF = (GR_T + GR_JT) * 32 * GR_ROW;  // floats of one stage buffer (job rows, then pose rows)
 constexpr size_t GR_LDS = ((size_t)2 * GR_BUF + 2 * GR_JT * 32 /*cls*/ + 2 * GR_MP * GR_PR * 5 /*records*/ + 2 * GR_PR /*coverage*/ +
                            64 /*pixel list*/ + GR_JT * 32 /*job ids*/) * sizeof(float);
+// ---- pose order of the record store.  The contraction skips a (32-pose tile, pixel) none of whose poses covers the
+// pixel, and a pixel no pose of a 128-pose block covers; in grid order a tile is the in-plane rotations x distances
+// of one viewpoint and 85 % of the (tile, pixel) pairs stay live at 44 % coverage.  Poses with alike silhouettes are
+// therefore stored next to each other (56 % live, tools/pose_grouping_probe.py): every pose gets a signature -- one
+// bit per B x B block of the window, set when the pose covers a pixel of the block -- and tiles are grown greedily:
+// the free pose of largest covered area is the seed, the 31 free poses at the smallest Hamming distance join it (ties:
+// lowest pose index).  Results do not depend on the order: a pose's losses are its own column of the products, and a
+// skipped product is an exact zero.  perm[slot] = pose, slot_of[pose] = slot, per pair.
+constexpr int RG_W = 16;   // signature words: at most 512 blocks
+__global__ void iota_mod_kernel(size_t n, int G, int32_t *a, int32_t *b) {   // grid order: slot = pose
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) a[k] = b[k] = (int32_t)(k % (size_t)G);
+}
+__global__ void rec_sig_kernel(int win_w, int B, int blocks_per_row, size_t stride, const uint32_t *list, const int32_t *cnt,
+                               uint32_t *sig) {
+  __shared__ uint32_t bits[RG_W];
+  const size_t pp = blockIdx.x;   // pair * G + pose
+  if (threadIdx.x < RG_W) bits[threadIdx.x] = 0u;
+  __syncthreads();
+  const int n = cnt[pp];
+  const uint32_t *l = list + pp * stride;
+  for (int k = threadIdx.x; k < n; k += blockDim.x) {
+    const int pix = (int)(l[k] & 0xffffu), r = pix / win_w, c = pix - r * win_w;
+    const int b = (r / B) * blocks_per_row + c / B;
+    atomicOr(&bits[b >> 5], 1u << (b & 31));
+  }
+  __syncthreads();
+  if (threadIdx.x < RG_W) sig[pp * RG_W + threadIdx.x] = bits[threadIdx.x];
+}
+
+// One workgroup per pair.  Thread t owns the contiguous poses [t q, (t + 1) q), q = ceil(G / 1024) <= 64 (G <= 65536),
+// so "lowest pose index first" is thread order, then order inside the thread.
+__global__ __launch_bounds__(1024) void rec_group_kernel(int G, const uint32_t *sig, const int32_t *cnt, int32_t *perm, int32_t *slot_of) {
+  __shared__ uint32_t seed_sig[RG_W];
+  __shared__ int hist[RG_W * 32 + 1];
+  __shared__ int wtot[16];
+  __shared__ long long wbest[16];
+  __shared__ int s_t, s_quota;
+  const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  sig += (size_t)pair * G * RG_W; cnt += (size_t)pair * G; perm += (size_t)pair * G; slot_of += (size_t)pair * G;
+  const int q = (G + 1023) / 1024;
+  const int gb = min(G, tid * q), nown = min(G, gb + q) - gb;
+  u64 freem = nown >= 64 ? ~0ull : ((1ull << nown) - 1ull);
+  auto dist = [&](int g) {
+    const uint4 *sp = (const uint4 *)(sig + (size_t)g * RG_W);
+    int d = 0;
+#pragma unroll
+    for (int w4 = 0; w4 < RG_W / 4; ++w4) {
+      const uint4 v = sp[w4];
+      d += __builtin_popcount(v.x ^ seed_sig[4 * w4]) + __builtin_popcount(v.y ^ seed_sig[4 * w4 + 1]) +
+           __builtin_popcount(v.z ^ seed_sig[4 * w4 + 2]) + __builtin_popcount(v.w ^ seed_sig[4 * w4 + 3]);
+    }
+    return d;
+  };
+  // block-wide exclusive prefix of one int per thread, in thread order (two barriers)
+  auto block_excl = [&](int v) {
+    const int inc = wave_scan_incl(v, lane);
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wave; ++w) off += wtot[w];
+    __syncthreads();
+    return off + inc - v;
+  };
+  for (int base = 0; base < G; base += 32) {
+    const int need = min(32, G - base);
+    // ---- seed: the free pose of largest covered area, lowest index on ties
+    long long best = -1;
+    for (int j = 0; j < nown; ++j)
+      if ((freem >> j) & 1ull) best = max(best, ((long long)cnt[gb + j] << 32) | (long long)(0x7fffffff - (gb + j)));
+    for (int o = 32; o >= 1; o >>= 1) best = max(best, __shfl_xor(best, o));
+    if (lane == 0) wbest[wave] = best;
+    for (int k = tid; k <= RG_W * 32; k += 1024) hist[k] = 0;
+    __syncthreads();
+    long long bb = wbest[0];
+    for (int w = 1; w < 16; ++w) bb = max(bb, wbest[w]);
+    const int seed = 0x7fffffff - (int)(bb & 0x7fffffffll);
+    if (tid < RG_W) seed_sig[tid] = sig[(size_t)seed * RG_W + tid];
+    __syncthreads();
+    // ---- histogram of the distances of the free poses, then the distance t the tile fills up at
+    for (int j = 0; j < nown; ++j)
+      if ((freem >> j) & 1ull) atomicAdd(&hist[dist(gb + j)], 1);
+    __syncthreads();
+    if (tid == 0) {
+      int cum = 0, t = 0;
+      for (; t < RG_W * 32; ++t) {
+        if (cum + hist[t] >= need) break;
+        cum += hist[t];
+      }
+      s_t = t; s_quota = need - cum;   // poses nearer than t all join; s_quota of those AT t do, lowest index first
+    }
+    __syncthreads();
+    const int t = s_t, quota = s_quota;
+    int c_lt = 0, c_eq = 0;
+    for (int j = 0; j < nown; ++j)
+      if ((freem >> j) & 1ull) {
+        const int d = dist(gb + j);
+        c_lt += d < t; c_eq += d == t;
+      }
+    const int eq_before = block_excl(c_eq);
+    const int a_eq = max(0, min(c_eq, quota - eq_before));
+    int slot = base + block_excl(c_lt + a_eq);
+    int eq_taken = 0;
+    for (int j = 0; j < nown; ++j)
+      if ((freem >> j) & 1ull) {
+        const int d = dist(gb + j);
+        const bool take = d < t || (d == t && eq_taken < a_eq);
+        if (d == t && take) ++eq_taken;
+        if (take) {
+          perm[slot] = gb + j; slot_of[gb + j] = slot; ++slot;
+          freem &= ~(1ull << j);
+        }
+      }
+    __syncthreads();
+  }
+}
+
 // Per (pair, block of GR_PR poses, chunk of 64 pixels): which pixels does ANY pose of the block cover.  The contraction
 // visits only those (the others contribute nothing to any loss of the block).
 __global__ void rec_mask_kernel(int G, int n_pb, int n_chunks, size_t hw, const RecVid *vid, u64 *mask) {
@@ -322,6 +439,15 @@ __global__ __launch_bounds__(GR_NT) void grid_mfma_rec_kernel(int hw, int N, int
 #ifndef NEMO_GR_ABL
 #define NEMO_GR_ABL 0
 #endif
+  // The staging waves are the younger half of the workgroup and would lose every issue arbitration to the matrix waves
+  // of their SIMD; a static priority for them is worth 4.5 % (0.195 -> 0.186 s; priority 3 the same, priority for the
+  // matrix waves nothing -- profiles/r03_dense_grid_records.md).
+#ifndef NEMO_GR_PRIO
+#define NEMO_GR_PRIO 1
+#endif
+  if (NEMO_GR_PRIO == 1 && !matrix) __builtin_amdgcn_s_setprio(1);
+  if (NEMO_GR_PRIO == 2 && !matrix) __builtin_amdgcn_s_setprio(3);
+  if (NEMO_GR_PRIO == 3 && matrix) __builtin_amdgcn_s_setprio(1);
   __syncthreads();
   for (int tg = 0; tg < ns; tg += JT * 32) {
     if (matrix) {
@@ -350,7 +476,13 @@ __global__ __launch_bounds__(GR_NT) void grid_mfma_rec_kernel(int hw, int N, int
       __syncthreads();   // the staging waves read the records
       __syncthreads();   // ... and have written the rows of stage 0
       f16v acc;
+#ifdef NEMO_GR_STAMP
+      unsigned long long tb_ = 0, t00_ = __builtin_readcyclecounter(), tm_ = 0;
+#endif
       for (int s = 0; s < n_stage; ++s) {
+#ifdef NEMO_GR_STAMP
+        const unsigned long long t0_ = __builtin_readcyclecounter();
+#endif
         const int pos = s / NKS, ks = s - pos * NKS;
         if (ks == 0) {
 #pragma unroll
@@ -396,8 +528,17 @@ __global__ __launch_bounds__(GR_NT) void grid_mfma_rec_kernel(int hw, int N, int
             }
           }
         }
+#ifdef NEMO_GR_STAMP
+        tb_ += __builtin_readcyclecounter() - t0_;
+        tm_ += live ? 1 : 0;
+#endif
         __syncthreads();  // stage s has been consumed, stage s + 1 is in place
       }
+#ifdef NEMO_GR_STAMP
+      if (blockIdx.x % 977 == 5 && lane == 0 && tg == 0 && (wave == 0 || wave == 5))
+        printf("wg %d matrix wave %d: busy %llu of %llu cycles, %d stages, %llu live\n", (int)blockIdx.x, wave, tb_,
+               __builtin_readcyclecounter() - t00_, n_stage, tm_);
+#endif
       const int g = g0 + pt * 32 + i;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -480,7 +621,13 @@ __global__ __launch_bounds__(GR_NT) void grid_mfma_rec_kernel(int hw, int N, int
       build_issue(0);
       build_put(0);
       __syncthreads();
+#ifdef NEMO_GR_STAMP
+      unsigned long long tb_ = 0, t00_ = __builtin_readcyclecounter(), tw_ = 0;
+#endif
       for (int s = 0; s < n_stage; ++s) {
+#ifdef NEMO_GR_STAMP
+        const unsigned long long t0_ = __builtin_readcyclecounter();
+#endif
         if (s + 1 < n_stage && !(NEMO_GR_ABL & 4)) {
           build_issue(s + 1);                    // 3 NRB loads (L2)
           __builtin_amdgcn_sched_barrier(0);
@@ -488,10 +635,24 @@ __global__ __launch_bounds__(GR_NT) void grid_mfma_rec_kernel(int hw, int N, int
           __builtin_amdgcn_sched_barrier(0);
           fetch(min(s + 2, n_stage - 1));        // NRA + 1 loads (HBM), younger than the bank rows build_put waits for
           __builtin_amdgcn_sched_barrier(0);
+#ifdef NEMO_GR_STAMP
+          const unsigned long long t1_ = __builtin_readcyclecounter();
+#endif
           build_put(s + 1);
+#ifdef NEMO_GR_STAMP
+          tw_ += __builtin_readcyclecounter() - t1_;
+#endif
         }
+#ifdef NEMO_GR_STAMP
+        tb_ += __builtin_readcyclecounter() - t0_;
+#endif
         __syncthreads();
       }
+#ifdef NEMO_GR_STAMP
+      if (blockIdx.x % 977 == 5 && lane == 0 && tg == 0 && (wave == 8 || wave == 13))
+        printf("wg %d staging wave %d: busy %llu of %llu cycles (build_put incl. its wait %llu), %d stages\n", (int)blockIdx.x, wave,
+               tb_, __builtin_readcyclecounter() - t00_, tw_, n_stage);
+#endif
     }
     __syncthreads();  // the next pass restages the LDS
   }
@@ -502,7 +663,7 @@ __global__ __launch_bounds__(256) void grid_finish_kernel(int hw, float inv_hw, 
                                                           const int32_t *img_idx, const int32_t *job_slot,
                                                           const float *clu, const float *partial,
                                                           const int32_t *pre_cnt, float *losses, u64 *counter,
-                                                          int clutter_on) {
+                                                          int clutter_on, const int32_t *perm) {
   __shared__ double red[256];
   const int n = blockIdx.x, tid = threadIdx.x;
   const int sl = job_slot[n];
@@ -523,7 +684,8 @@ __global__ __launch_bounds__(256) void grid_finish_kernel(int hw, float inv_hw, 
   for (int g = tid; g < G; g += 256) {
     float s = 0.0f;
     for (int c = 0; c < n_chunks; ++c) s += partial[((size_t)c * N + n) * G + g];
-    losses[(size_t)n * G + g] = K - inv_hw * s;
+    // the record store keeps its poses in slot order (perm[slot] = pose); losses are reported in grid order
+    losses[(size_t)n * G + (perm ? perm[(size_t)sl * G + g] : g)] = K - inv_hw * s;
     cov += (u64)pre_cnt[(size_t)sl * G + g];
   }
   if (counter && cov) atomicAdd(counter, cov);

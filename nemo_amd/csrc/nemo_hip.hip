@@ -59,6 +59,8 @@ struct nemo_ctx {
   RecVid *d_pre_vid;  // records [pairs][G][h*w] (vertex ids + covered flag) and their barycentrics [..][3] for the
   float *d_pre_bary;  // record-based matrix-core grid search (dense grids: no materialised renders), or null
   u64 *d_pre_mask;    // [pairs][pose blocks of GR_PR][pixel chunks]: pixels covered by any pose of the block
+  int32_t *d_pre_perm, *d_pre_slotof;  // [pairs][G]: the record store's pose order (slot -> pose, pose -> slot)
+  int env_grid_group;  // NEMO_GRID_GROUP=0: record store in grid order (no grouping of alike poses)
   float *d_pre_maps;  // dense renders [pairs][pre_block][h*w][D] for the MFMA grid search, or null (no store / large meshes)
   int pre_block;      // poses per pair held by d_pre_maps: pre_G (whole grid resident) or a block of it (rendered per call)
   // block render scratch (job = (pair, pose of the block)); in the resident case freed once the maps are rendered
@@ -82,7 +84,7 @@ struct nemo_ctx {
   int n_cu;              // its compute-unit count (cached: hipGetDeviceProperties is slow)
   // environment switches, read ONCE in nemo_ctx_create (hot calls never call getenv)
   int env_grid_no_mfma, env_solve_stagger, env_solve_order, env_solve_affinity, env_slot_identity;
-  int env_grid_records;  // NEMO_GRID_RECORDS: -1 (default) the record store when the dense renders do not fit; 0 never; 1 whenever it fits
+  int env_grid_records;  // NEMO_GRID_RECORDS: -1 (default) the record store when the dense renders do not fit or G >= 4096; 0 never; 1 whenever it fits
   double env_prerender_map_gb;
   char err[512];
 };
@@ -340,6 +342,7 @@ int nemo_ctx_create(const nemo_config *cfg, nemo_ctx **out) {
   ctx->env_solve_affinity = env_int("NEMO_SOLVE_AFFINITY", 1);
   ctx->env_slot_identity = env_int("NEMO_SLOT_ORDER", 1) == 0;
   ctx->env_grid_records = env_int("NEMO_GRID_RECORDS", -1);
+  ctx->env_grid_group = env_int("NEMO_GRID_GROUP", 1);
   {
     const char *v = getenv("NEMO_PRERENDER_MAP_GB");
     ctx->env_prerender_map_gb = v ? atof(v) : 48.0;
@@ -407,7 +410,7 @@ int nemo_ctx_destroy(nemo_ctx *ctx) {
   hipFree(ctx->d_counter);
   hipFree(ctx->d_adam);
   hipFree(ctx->d_pre_slot); hipFree(ctx->d_pre_cnt); hipFree(ctx->d_pre_pairs); hipFree(ctx->d_pre_list);
-  hipFree(ctx->d_pre_vid); hipFree(ctx->d_pre_bary); hipFree(ctx->d_pre_mask);
+  hipFree(ctx->d_pre_vid); hipFree(ctx->d_pre_bary); hipFree(ctx->d_pre_mask); hipFree(ctx->d_pre_perm); hipFree(ctx->d_pre_slotof);
   hipFree(ctx->d_pre_maps); hipFree(ctx->d_gs_order); hipFree(ctx->d_gs_start); hipFree(ctx->d_gs_jobslot);
   hipFree(ctx->d_gs_partial); hipFree(ctx->d_gs_work); hipFree(ctx->d_big); hipFree(ctx->d_so);
   for (int i = 0; i < ctx->n_meshes; ++i) hipFree(ctx->d_slot_order[i]);
@@ -584,7 +587,8 @@ int nemo_grid_search(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const i
                          ctx->d_gs_start, d_feat, d_clu, (const MeshDesc *)ctx->d_meshes, (const int32_t *)ctx->d_pre_pairs,
                          (const RecVid *)ctx->d_pre_vid, (const float *)ctx->d_pre_bary, ctx->d_gs_partial, (const u64 *)ctx->d_pre_mask, n_pb, con);
     hipLaunchKernelGGL(grid_finish_kernel, dim3(N), dim3(256), 0, st, hw, ctx->P.inv_hw, N, G, n_chunks, d_img_idx,
-                       ctx->d_gs_jobslot, d_clu, ctx->d_gs_partial, ctx->d_pre_cnt, d_losses, ctx->d_counter, con);
+                       ctx->d_gs_jobslot, d_clu, ctx->d_gs_partial, ctx->d_pre_cnt, d_losses, ctx->d_counter, con,
+                       (const int32_t *)ctx->d_pre_perm);
     HIP_TRY(ctx, hipGetLastError());
   } else if (mfma) {
     // matrix-core path over the dense pre-rendered maps; jobs without a stored pair fall through to grid_kernel
@@ -622,7 +626,8 @@ int nemo_grid_search(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const i
                            ctx->d_blk_live, con);
     }
     hipLaunchKernelGGL(grid_finish_kernel, dim3(N), dim3(256), 0, st, hw, ctx->P.inv_hw, N, G, n_chunks, d_img_idx,
-                       ctx->d_gs_jobslot, d_clu, ctx->d_gs_partial, ctx->d_pre_cnt, d_losses, ctx->d_counter, con);
+                       ctx->d_gs_jobslot, d_clu, ctx->d_gs_partial, ctx->d_pre_cnt, d_losses, ctx->d_counter, con,
+                       (const int32_t *)nullptr);
     HIP_TRY(ctx, hipGetLastError());
   }
   if (d_work) {
@@ -660,7 +665,8 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
   if (!ctx) return fail(nullptr, NEMO_ERR_ARG, "nemo_grid_prerender: null ctx");
   hipFree(ctx->d_pre_slot); hipFree(ctx->d_pre_cnt); hipFree(ctx->d_pre_pairs); hipFree(ctx->d_pre_list);
   hipFree(ctx->d_pre_maps); hipFree(ctx->d_pre_vid); hipFree(ctx->d_pre_bary); hipFree(ctx->d_pre_mask);
-  ctx->d_pre_mask = nullptr;
+  hipFree(ctx->d_pre_perm); hipFree(ctx->d_pre_slotof);
+  ctx->d_pre_mask = nullptr; ctx->d_pre_perm = ctx->d_pre_slotof = nullptr;
   free_block_scratch(ctx, false);
   ctx->pre_block = 0;
   ctx->d_pre_slot = ctx->d_pre_cnt = ctx->d_pre_pairs = nullptr;
@@ -709,12 +715,13 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
   // from which grid_mfma_rec_kernel builds the rendered rows on the fly.  Rendered here in slices of poses through a
   // temporary pix_to_face / bary buffer (campos -> rasterize -> pack).  Ordinary (LDS-table) meshes only.
   // Chosen when the dense renders of all G poses exceed the budget and the records do not (measured, BASELINE config 4:
-  // 12 classes x 9720 poses, 0.277 s against 0.455 s for block-after-block rendering; when the renders fit they are
-  // the faster operand, 0.197 s against 0.227 s for one class -- profiles/r03_dense_grid_records.md).
+  // 12 classes x 9720 poses, 0.221 s against 0.453 s for block-after-block rendering), and for grids of 4096 poses or
+  // more even when the renders would fit (one class x 9720 poses: 0.186 s and 1.6 GB against 0.196 s and 40 GB; at 144
+  // poses the renders are the faster operand, 4.5 against 7.7 ms) -- profiles/r03_dense_grid_records.md.
   const double map_budget = ctx->env_prerender_map_gb * 1073741824.0;
   const bool maps_fit = (double)n_pairs * G * stride * ctx->cfg.feat_dim * 4.0 <= map_budget;
   if (n_pairs <= GP_MAX_PAIRS && !ctx->P.big && !ctx->env_grid_no_mfma && (double)n_pairs * G * stride * 20.0 <= map_budget &&
-      (ctx->env_grid_records > 0 || (ctx->env_grid_records < 0 && !maps_fit))) {
+      (ctx->env_grid_records > 0 || (ctx->env_grid_records < 0 && (!maps_fit || G >= 4096)))) {
     const size_t n_rec = (size_t)n_pairs * G * stride;
     const int n_chunks = (int)((stride + GP_PIX - 1) / GP_PIX);
     long gb = (long)((2048.0 * 1048576.0) / ((double)n_pairs * stride * 16.0));   // about 2 GiB of scratch per slice
@@ -732,6 +739,25 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
     if (e == hipSuccess) e = hipMalloc(&ctx->d_blk_p2f, jobs * stride * 4);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_blk_bary, jobs * stride * 12);
     hipStream_t st = (hipStream_t)stream;
+    // the store's pose order: alike silhouettes next to each other (rec_group_kernel), from the lists just rendered
+    uint32_t *d_sig = nullptr;
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_pre_perm, sizeof(int32_t) * (size_t)n_pairs * G);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_pre_slotof, sizeof(int32_t) * (size_t)n_pairs * G);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_sig, sizeof(uint32_t) * RG_W * (size_t)n_pairs * G);
+    if (e == hipSuccess) {
+      if (ctx->env_grid_group && G <= 65536) {
+        int B = 8;
+        while (((ctx->cfg.win_h + B - 1) / B) * ((ctx->cfg.win_w + B - 1) / B) > RG_W * 32) B *= 2;
+        hipLaunchKernelGGL(rec_sig_kernel, dim3((unsigned)((size_t)n_pairs * G)), dim3(256), 0, st, ctx->cfg.win_w, B,
+                           (ctx->cfg.win_w + B - 1) / B, stride, (const uint32_t *)ctx->d_pre_list, (const int32_t *)ctx->d_pre_cnt, d_sig);
+        hipLaunchKernelGGL(rec_group_kernel, dim3((unsigned)n_pairs), dim3(1024), 0, st, (int)G, (const uint32_t *)d_sig,
+                           (const int32_t *)ctx->d_pre_cnt, ctx->d_pre_perm, ctx->d_pre_slotof);
+      } else {
+        hipLaunchKernelGGL(iota_mod_kernel, dim3((unsigned)(((size_t)n_pairs * G + 255) / 256)), dim3(256), 0, st, (size_t)n_pairs * G,
+                           (int)G, ctx->d_pre_perm, ctx->d_pre_slotof);
+      }
+      e = hipGetLastError();
+    }
     for (long g0 = 0; e == hipSuccess && g0 < G; g0 += gb) {
       const int nb = (int)(G - g0 < gb ? G - g0 : gb);
       const size_t nj = (size_t)n_pairs * nb;
@@ -746,7 +772,7 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
       const size_t npix = nj * stride;
       hipLaunchKernelGGL(pack_rec_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, npix, stride, (int)G, (int)g0, nb,
                          (const MeshDesc *)ctx->d_meshes, (const int32_t *)ctx->d_blk_mesh, (const int32_t *)ctx->d_blk_p2f,
-                         (const float *)ctx->d_blk_bary, ctx->d_pre_vid, ctx->d_pre_bary);
+                         (const float *)ctx->d_blk_bary, (const int32_t *)ctx->d_pre_slotof, ctx->d_pre_vid, ctx->d_pre_bary);
       e = hipGetLastError();
     }
     const int n_pb = (int)((G + GR_PR - 1) / GR_PR);
@@ -758,9 +784,10 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     free_block_scratch(ctx, false);
+    hipFree(d_sig);
     if (e != hipSuccess) {
-      hipFree(ctx->d_pre_vid); hipFree(ctx->d_pre_bary); hipFree(ctx->d_pre_mask);
-      ctx->d_pre_vid = nullptr; ctx->d_pre_bary = nullptr; ctx->d_pre_mask = nullptr;
+      hipFree(ctx->d_pre_vid); hipFree(ctx->d_pre_bary); hipFree(ctx->d_pre_mask); hipFree(ctx->d_pre_perm); hipFree(ctx->d_pre_slotof);
+      ctx->d_pre_vid = nullptr; ctx->d_pre_bary = nullptr; ctx->d_pre_mask = nullptr; ctx->d_pre_perm = ctx->d_pre_slotof = nullptr;
       return hip_fail(ctx, e, "nemo_grid_prerender: record store");
     }
     return NEMO_OK;

@@ -1318,12 +1318,13 @@ def test_dense_grid_tiled_over_pose_blocks(oracle, monkeypatch):
         assert best[k] == bo
 
 
-@pytest.mark.parametrize('D,clutter', [(128, False), (256, True)])
-def test_dense_grid_record_store(oracle, monkeypatch, D, clutter):
-    """The record-based matrix-core grid search (no materialised renders) on its own: 256-d features (two feature
-    halves per pixel) and the loss without clutter, more jobs than one 64-job pass, a window whose last pixel chunk
-    is partial, against the oracle."""
+@pytest.mark.parametrize('D,clutter,group', [(128, False, '1'), (256, True, '1'), (128, True, '0')])
+def test_dense_grid_record_store(oracle, monkeypatch, D, clutter, group):
+    """The record-based matrix-core grid search (no materialised renders) on its own: 256-d features (four feature
+    slices per pixel) and the loss without clutter, more jobs than one 64-job pass, a window whose last pixel chunk
+    is partial, the store with alike poses grouped (default) and in grid order, against the oracle."""
     monkeypatch.setenv('NEMO_GRID_RECORDS', '1')
+    monkeypatch.setenv('NEMO_GRID_GROUP', group)
     sc = make_scene(image_hw=(136, 200), number_vertices=150, n_img=3, seed=43, D=D, clutter=clutter)
     assert (sc.cfg.h * sc.cfg.w) % 64 != 0
     eng = _engine(sc)
@@ -1340,6 +1341,47 @@ def test_dense_grid_record_store(oracle, monkeypatch, D, clutter):
         bo, lo = oracle.grid_search(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[i], sc.clus[i] if clutter else None, gC, gth)
         for k in range(i, n, 3):
             assert np.abs(losses[k] - lo).max() <= REL * np.abs(lo).max() and best[k] == bo
+
+
+def test_dense_grid_record_store_ragged(oracle, monkeypatch):
+    """Record store edge cases: three stored pairs of which the middle one has no job in the call, a grid of 50 poses
+    (less than one 128-pose block, not a multiple of the 32-pose tile), a pose that covers nothing (camera far off to
+    the side: an all-zero signature for the grouping), one job only for the last pair; equal bit for bit to the dense
+    renders and to the store in grid order, and against the oracle."""
+    from nemo_amd.engine import PoseEngine
+    a = make_scene('car', n_img=2, seed=91)
+    b = make_scene('bus', n_img=1, seed=92, number_vertices=300)
+    gA = syn.pose_grid(a.distance, n_azim=5, n_elev=5, n_theta=2)
+    gB = syn.pose_grid(b.distance, n_azim=5, n_elev=5, n_theta=2)
+    G = len(gA[1])
+    assert G == 50
+    gA[0][7] = gA[0][7] * 40.0                      # far away: the object shrinks under a pixel centre or to nothing
+    dC, dth = _dev(np.stack([gA[0], gB[0]])), _dev(np.stack([gA[1], gB[1]]))
+    feats, clus = _dev(np.concatenate([a.feats, b.feats])), _dev(np.concatenate([a.clus, b.clus]))
+    img = _dev([0, 1, 0, 2], torch.int32)
+    mesh = _dev([0, 0, 0, 2], torch.int32)          # mesh 1 (a copy of mesh 0's class) is stored but unused
+    grid = _dev([0, 0, 0, 1], torch.int32)
+    out = {}
+    for mode, env in (('maps', {'NEMO_GRID_RECORDS': '0'}), ('records', {'NEMO_GRID_RECORDS': '1'}),
+                      ('grid_order', {'NEMO_GRID_RECORDS': '1', 'NEMO_GRID_GROUP': '0'})):
+        for k in ('NEMO_GRID_RECORDS', 'NEMO_GRID_GROUP'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = PoseEngine(a.geo.S, (a.geo.h, a.geo.w), a.D)
+        eng.register_mesh(a.verts, a.faces, a.bank)
+        eng.register_mesh(a.verts, a.faces, a.bank)
+        eng.register_mesh(b.verts, b.faces, b.bank)
+        eng.grid_prerender(dC, dth, [(0, 0), (1, 0), (2, 1)])
+        assert eng.grid_store_kind() == ('dense_maps' if mode == 'maps' else 'records')
+        out[mode] = eng.grid_search(feats, clus, dC, dth, img_idx=img, mesh_idx=mesh, grid_idx=grid)
+    for mode in ('records', 'grid_order'):
+        assert torch.equal(out[mode][3], out['maps'][3]) and torch.equal(out[mode][2], out['maps'][2])
+    best, losses = out['records'][2].cpu().numpy(), out['records'][3].cpu().numpy()
+    assert np.isfinite(losses).all()
+    for k, (sc, i, g) in enumerate([(a, 0, gA), (a, 1, gA), (a, 0, gA), (b, 0, gB)]):
+        bo, lo = oracle.grid_search(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[i], sc.clus[i], g[0], g[1])
+        assert np.abs(losses[k] - lo).max() <= REL * np.abs(lo).max() and best[k] == bo
 
 
 def test_large_mesh_256d_double_resolution(oracle):
