@@ -303,6 +303,15 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
     const unsigned slot = (blockIdx.x * 0x9E3779B1u) >> 25;  // 0..127, well mixed
     for (unsigned i = 0; i < slot * stagger; ++i) __builtin_amdgcn_s_sleep(127);
   }
+#ifdef NEMO_SOLVE_PRIO
+  {
+    const int w_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if ((NEMO_SOLVE_PRIO == 1 || NEMO_SOLVE_PRIO == 5) && w_ >= 8) __builtin_amdgcn_s_setprio(1);
+    if (NEMO_SOLVE_PRIO == 2 && w_ >= 8) __builtin_amdgcn_s_setprio(3);
+    if ((NEMO_SOLVE_PRIO == 3 || NEMO_SOLVE_PRIO == 5) && w_ == 0) __builtin_amdgcn_s_setprio(3);
+    if (NEMO_SOLVE_PRIO == 4 && w_ >= 12) __builtin_amdgcn_s_setprio(1);
+  }
+#endif
   load_world_verts<BIG>(P, L, M);
   loss_constant(P, L, c);
   const bool lead = threadIdx.x == 0;
