@@ -212,14 +212,11 @@ __global__ __launch_bounds__(1024) void grid_mfma_lds_kernel(int hw, int N, int 
 // record: three 16-bit vertex ids + a covered flag, three barycentrics -- and the kernel below builds the pose
 // operand of the per-pixel GEMM in LDS from the records and the (L2-resident) vertex bank:
 //   row(g, p) = (b0 * bank[v0] + b1 * bank[v1]) + b2 * bank[v2]     (the arithmetic of interpolate_kernel, bit for bit)
-// Work split inside the 512-thread workgroup (128 poses x 64 jobs per pass; 8 waves so that a builder's 16 row
-// fragments fit its 256 registers):
-//   waves 0-3 stage the jobs' feature rows (HBM) and the records (HBM) one pixel ahead, as grid_mfma_lds_kernel does;
-//   waves 4-7 build the 128 pose rows of the NEXT pixel in rounds of bank-row loads (L2) placed between the operand
-//             steps of the CURRENT pixel's matrix instructions -- their vector-memory queue holds nothing but those
-//             loads, so a round never waits behind an HBM load (the counter is in order);
-//   all 8 waves multiply: wave w owns (job tile w / 4, pose tile w % 4); a tile whose 32 poses do not cover the
-//   pixel is skipped (all its products are zero and so are its loss terms).
+// A workgroup owns (pair, 64 pixels, a block of GR_PR poses) and takes the pair's jobs 64 at a time.  It works in stages
+// of (listed pixel, 64 features) through two LDS stage buffers with ONE barrier per stage, and its waves have two roles
+// (grid_mfma_rec_kernel): matrix waves multiply stage s while staging waves build the pose rows of stage s + 1 and
+// move the feature rows of stage s + 2.  Two 512-thread workgroups share a CU (76 KB of LDS and 128 VGPRs each): a
+// stage lasts as long as the slowest of its waves, and the other workgroup's waves fill the pipes meanwhile.
 // pack_rec_kernel turns the rasteriser's (pix_to_face, bary) of a block of poses into the records.
 struct RecVid { uint32_t v01, v2c; };  // v0 | v1 << 16, v2 | covered << 16
 __global__ void pack_rec_kernel(size_t npix, size_t hw, int G, int g0, int gb, const MeshDesc *meshes, const int32_t *mesh_of_job,
@@ -242,18 +239,24 @@ __global__ void pack_rec_kernel(size_t npix, size_t hw, int G, int g0, int gb, c
   bout[3 * dst] = b0; bout[3 * dst + 1] = b1; bout[3 * dst + 2] = b2;
 }
 
-constexpr int GR_T = 4;    // pose tiles per workgroup (128 poses)
-constexpr int GR_JT = 2;   // job tiles per pass (64 jobs)
-constexpr int GR_MP = 4;   // listed pixels per staged group of records
-constexpr int GR_PR = GR_T * 32;
-constexpr int GR_NT = 1024; // 16 waves: 8 matrix waves, 8 staging waves
+#ifndef NEMO_GR_SMALL
+#define NEMO_GR_SMALL 1
+#endif
+// Shape.  Default: 64 poses x 64 jobs per workgroup, 512 threads, two workgroups per CU (their barriers are independent:
+// 0.152 s against 0.186 s for the dense one-class grid).  NEMO_GR_SMALL=0: 128 poses, 1024 threads, one workgroup per CU.
+constexpr int GR_T = NEMO_GR_SMALL ? 2 : 4;    // pose tiles per workgroup
+constexpr int GR_JT = 2;                       // job tiles per pass (64 jobs)
+constexpr int GR_MP = NEMO_GR_SMALL ? 2 : 4;   // listed pixels per staged group of records
+constexpr int GR_PR = GR_T * 32;               // poses per workgroup
+constexpr int GR_NT = GR_T * GR_JT * 128;      // one matrix wave per (job tile, pose tile) and as many staging waves
+constexpr int GR_SR = GR_NT / 32;              // rows one pass of the staging threads covers (16 lanes per row)
 constexpr int GR_KS = 64;  // features per stage: a stage is (listed pixel, 64-feature slice)
 constexpr int GR_ROW = GR_KS + 4;  // padded LDS row: the 16-byte operand reads of a 16-lane group are conflict-free
 constexpr int GR_BUF = (GR_T + GR_JT) * 32 * GR_ROW;  // floats of one stage buffer (job rows, then pose rows)
 constexpr size_t GR_LDS = ((size_t)2 * GR_BUF + 2 * GR_JT * 32 /*cls*/ + 2 * GR_MP * GR_PR * 5 /*records*/ + 2 * GR_PR /*coverage*/ +
                            64 /*pixel list*/ + GR_JT * 32 /*job ids*/) * sizeof(float);
 // ---- pose order of the record store.  The contraction skips a (32-pose tile, pixel) none of whose poses covers the
-// pixel, and a pixel no pose of a 128-pose block covers; in grid order a tile is the in-plane rotations x distances
+// pixel, and a pixel no pose of the workgroup's block covers; in grid order a tile is the in-plane rotations x distances
 // of one viewpoint and 85 % of the (tile, pixel) pairs stay live at 44 % coverage.  Poses with alike silhouettes are
 // therefore stored next to each other (56 % live, tools/pose_grouping_probe.py): every pose gets a signature -- one
 // bit per B x B block of the window, set when the pose covers a pixel of the block -- and tiles are grown greedily:
@@ -382,7 +385,7 @@ __global__ void rec_mask_kernel(int G, int n_pb, int n_chunks, size_t hw, const 
 }
 
 template <int D>
-__global__ __launch_bounds__(GR_NT) void grid_mfma_rec_kernel(int hw, int N, int G, int n_chunks, const int32_t *img_idx,
+__global__ __launch_bounds__(GR_NT, 4) void grid_mfma_rec_kernel(int hw, int N, int G, int n_chunks, const int32_t *img_idx,
                                                               const int32_t *order, const int32_t *slot_start,
                                                               const float *__restrict__ feat, const float *__restrict__ clu,
                                                               const MeshDesc *meshes, const int32_t *pair_mesh,
@@ -391,7 +394,8 @@ __global__ __launch_bounds__(GR_NT) void grid_mfma_rec_kernel(int hw, int N, int
                                                               int n_pb, int clutter_on) {
   extern __shared__ __align__(16) float gq_sm[];
   constexpr int NKS = D / GR_KS, T = GR_T, JT = GR_JT, PR = GR_PR, MP = GR_MP, ROW = GR_ROW;
-  constexpr int NRB = T, NRA = JT;  // row fragments per staging thread (rows srow + 32 k of the pose / the job slab)
+  constexpr int SR = GR_SR, NMW = T * JT;    // rows per staging pass; matrix waves
+  constexpr int NRB = PR / SR, NRA = JT * 32 / SR;  // row fragments per staging thread (rows srow + SR k of the pose / the job slab)
   constexpr int GS = MP * NKS;              // stages per group of records
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 31, half = lane >> 5;
@@ -424,16 +428,15 @@ __global__ __launch_bounds__(GR_NT) void grid_mfma_rec_kernel(int hw, int N, int
   if (tid < 64 && ((pmask >> tid) & 1ull)) plist[__builtin_popcountll(pmask & ((1ull << tid) - 1ull))] = tid;
   // Wave roles (two separate loops with the same barrier count, so that the register allocation is the maximum of the
   // two roles and not their sum):
-  //   waves 0-7, the MATRIX waves: wave w multiplies job tile w / 4 with pose tile w % 4 (two matrix waves per SIMD: the
-  //     one's LDS waits, loss updates and barrier arrival are covered by the other's matrix instructions) and, every MP
+  //   the first T * JT waves, the MATRIX waves: wave w multiplies job tile w / T with pose tile w % T and, every MP
   //     pixels, moves its share of the next group of records HBM -> LDS;
-  //   waves 8-15, the STAGING waves: build the 128 pose rows of the next stage from the records and the bank, and move
-  //     the 64 feature rows of the stage after next HBM -> registers -> LDS.  Their loads are unconditional and in a fixed
-  //     order, so the in-order memory counter lets them wait for the bank rows (L2) without waiting for the feature
-  //     rows (HBM) issued after them.
-  const bool matrix = wave < 8;
-  const int pt = wave & 3, jt = (wave >> 2) & 1;
-  const int t2 = tid - 512, srow = t2 >> 4, sc4 = t2 & 15;              // staging waves: rows srow + 32 k of a slab
+  //   the other T * JT waves, the STAGING waves: build the GR_PR pose rows of the next stage from the records and the
+  //     bank, and move the 64 feature rows of the stage after next HBM -> registers -> LDS.  Their loads are
+  //     unconditional and in a fixed order, so the in-order memory counter lets them wait for the bank rows (L2) without
+  //     waiting for the feature rows (HBM) issued after them.
+  const bool matrix = wave < NMW;
+  const int pt = wave % T, jt = (wave / T) % JT;
+  const int t2 = tid - NMW * 64, srow = t2 >> 4, sc4 = t2 & 15;              // staging waves: rows srow + SR k of a slab
   const int n_stage = npl * NKS;                                         // stage s = (listed pixel s / NKS, slice s % NKS)
   const gf4p feat4 = (gf4p)as_global(feat);
 #ifndef NEMO_GR_ABL
@@ -455,8 +458,10 @@ __global__ __launch_bounds__(GR_NT) void grid_mfma_rec_kernel(int hw, int N, int
       typedef float f3v __attribute__((ext_vector_type(3), aligned(4)));
       RecVid mvr;
       f3v mbr;
-      const int mpxs = tid % MP, mlds = mpxs * PR + tid / MP;
-      const size_t mbase = ((size_t)sl * G + min(g0 + tid / MP, G - 1)) * hw + p0;  // (the item's pose, pixel 0 of the chunk)
+      static_assert(MP * PR <= NMW * 64, "one record item per matrix thread");
+      const bool mine = tid < MP * PR;
+      const int mpxs = tid % MP, mlds = mpxs * PR + min(tid / MP, PR - 1);
+      const size_t mbase = ((size_t)sl * G + min(g0 + min(tid / MP, PR - 1), G - 1)) * hw + p0;  // (the item's pose, pixel 0 of the chunk)
       auto meta_fetch = [&](int grp) {
         const size_t idx = mbase + plist[min(grp * MP + mpxs, npl - 1)];
         mvr = vid[idx];
@@ -464,8 +469,10 @@ __global__ __launch_bounds__(GR_NT) void grid_mfma_rec_kernel(int hw, int N, int
       };
       auto meta_store = [&](int grp) {
         const int o = (grp & 1) * MP * PR + mlds;
-        mv01[o] = mvr.v01; mv2c[o] = mvr.v2c;
-        mb[o * 3] = mbr.x; mb[o * 3 + 1] = mbr.y; mb[o * 3 + 2] = mbr.z;
+        if (mine) {
+          mv01[o] = mvr.v01; mv2c[o] = mvr.v2c;
+          mb[o * 3] = mbr.x; mb[o * 3 + 1] = mbr.y; mb[o * 3 + 2] = mbr.z;
+        }
       };
       f16v lsum;
 #pragma unroll
@@ -550,7 +557,7 @@ __global__ __launch_bounds__(GR_NT) void grid_mfma_rec_kernel(int hw, int N, int
       uint32_t ro[NRA];   // feature rows of the pass's jobs at pixel 0 of the chunk
 #pragma unroll
       for (int k = 0; k < NRA; ++k) {
-        const int job = order[js + min(tg + srow + 32 * k, ns - 1)];
+        const int job = order[js + min(tg + srow + SR * k, ns - 1)];
         ro[k] = (uint32_t)((((size_t)(img_idx ? img_idx[job] : job) * hw + p0) * D) >> 2) + (uint32_t)sc4;
       }
       // the clutter score of job t2 at the stage's pixel (threads that stage none read a valid dummy: the load below is
@@ -573,7 +580,7 @@ __global__ __launch_bounds__(GR_NT) void grid_mfma_rec_kernel(int hw, int N, int
       auto put_rows = [&](int s) {   // the fetched fragments of stage s go to its buffer
         float *dst = gq_sm + (s & 1) * GR_BUF + srow * ROW + sc4 * 4;
 #pragma unroll
-        for (int k = 0; k < NRA; ++k) *(f4 *)&dst[32 * k * ROW] = st[k];
+        for (int k = 0; k < NRA; ++k) *(f4 *)&dst[SR * k * ROW] = st[k];
         if (s % NKS == 0 && has_cl) cls[((s / NKS) & 1) * JT * 32 + t2] = clv;
       };
       // the NRB pose-row fragments of the next stage = three bank rows each, weighted by the barycentrics
@@ -590,9 +597,9 @@ __global__ __launch_bounds__(GR_NT) void grid_mfma_rec_kernel(int hw, int N, int
         uint32_t ra[NRB], rb[NRB];
 #pragma unroll
         for (int k = 0; k < NRB; ++k) {   // every LDS read of the stage first ...
-          ra[k] = a_[32 * k]; rb[k] = b_[32 * k];
+          ra[k] = a_[SR * k]; rb[k] = b_[SR * k];
 #pragma unroll
-          for (int v = 0; v < 3; ++v) bw[v][k] = w_[3 * 32 * k + v];
+          for (int v = 0; v < 3; ++v) bw[v][k] = w_[3 * SR * k + v];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -603,14 +610,14 @@ __global__ __launch_bounds__(GR_NT) void grid_mfma_rec_kernel(int hw, int N, int
           for (int v = 0; v < 3; ++v) {
             m[v][k] = (NEMO_GR_ABL & 1) ? f4{0.f, 0.f, 0.f, 0.f} : *(gf4p)(bank + (vv[v] * (uint32_t)D + col));
           }
-          if (ks == 0 && sc4 == 0) c_[32 * k] = cov ? 1 : 0;
+          if (ks == 0 && sc4 == 0) c_[SR * k] = cov ? 1 : 0;
         }
       };
       auto build_put = [&](int s) {
         float *dst = gq_sm + (s & 1) * GR_BUF + (JT * 32 + srow) * ROW + sc4 * 4;
 #pragma unroll
         for (int k = 0; k < NRB; ++k)   // (b0 * r0 + b1 * r1) + b2 * r2: interpolate_kernel's arithmetic
-          *(f4 *)&dst[32 * k * ROW] = (bw[0][k] * m[0][k] + bw[1][k] * m[1][k]) + bw[2][k] * m[2][k];
+          *(f4 *)&dst[SR * k * ROW] = (bw[0][k] * m[0][k] + bw[1][k] * m[1][k]) + bw[2][k] * m[2][k];
       };
       // ---- prologue: the job ids of the pass, the feature rows of stages 0 and 1, the pose rows of stage 0
       if (t2 < JT * 32) ordl[t2] = order[js + min(tg + t2, ns - 1)];
