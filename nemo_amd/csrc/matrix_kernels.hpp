@@ -2,6 +2,7 @@
 // Part of the single translation unit nemo_hip.hip (included from there, in order; not a stand-alone header).
 #ifndef MATRIX_KERNELS_HPP
 #define MATRIX_KERNELS_HPP
+#include <type_traits>
 
 namespace {
 
@@ -253,8 +254,8 @@ constexpr int GR_SR = GR_NT / 32;              // rows one pass of the staging t
 constexpr int GR_KS = 64;  // features per stage: a stage is (listed pixel, 64-feature slice)
 constexpr int GR_ROW = GR_KS + 4;  // padded LDS row: the 16-byte operand reads of a 16-lane group are conflict-free
 constexpr int GR_BUF = (GR_T + GR_JT) * 32 * GR_ROW;  // floats of one stage buffer (job rows, then pose rows)
-constexpr size_t GR_LDS = ((size_t)2 * GR_BUF + 2 * GR_JT * 32 /*cls*/ + 2 * GR_MP * GR_PR * 5 /*records*/ + 2 * GR_PR /*coverage*/ +
-                           64 /*pixel list*/ + GR_JT * 32 /*job ids*/) * sizeof(float);
+constexpr size_t GR_LDS = ((size_t)2 * GR_BUF + 2 * 2 * GR_JT * 32 /*cls*/ + 2 * GR_MP * GR_PR * 5 /*records*/ + 2 * GR_PR /*coverage*/ +
+                           64 /*pixel list*/ + 2 * GR_JT * 32 /*job ids*/) * sizeof(float);
 // ---- pose order of the record store.  The contraction skips a (32-pose tile, pixel) none of whose poses covers the
 // pixel, and a pixel no pose of the workgroup's block covers; in grid order a tile is the in-plane rotations x distances
 // of one viewpoint and 85 % of the (tile, pixel) pairs stay live at 44 % coverage.  Poses with alike silhouettes are
@@ -417,23 +418,28 @@ __global__ __launch_bounds__(GR_NT, 4) void grid_mfma_rec_kernel(int hw, int N, 
     return;
   }
   const gf32p bank = as_global(meshes[pair_mesh[sl]].bank);
-  // LDS: two stage buffers (64 job rows + 128 pose rows of 64 features), so that stage s + 1 is written while the matrix
-  // instructions of stage s read the other buffer -- one barrier per stage, the matrix pipe does not wait for staging
-  float *cls = gq_sm + 2 * GR_BUF;                                      // [2][64] clutter scores of the jobs, by list parity
-  uint32_t *mv01 = (uint32_t *)(cls + 2 * JT * 32), *mv2c = mv01 + 2 * MP * PR;   // [2][MP * PR] records, by group parity
+  // LDS: the pose rows of a stage (GR_PR rows of 64 features) and the job rows of a SUB-STAGE (64 rows) are both double
+  // buffered.  A stage's pose rows serve NJ = 2 sub-stages -- two passes of 64 jobs -- so a pair with more than 64 jobs
+  // pays for the building of its pose rows once per 128 jobs; sub-stage u + 1 is written while the matrix
+  // instructions of sub-stage u read the other buffers: one barrier per sub-stage.
+  constexpr int NJ = 2;
+  constexpr int ABUF = JT * 32 * ROW, BBUF = PR * ROW;                  // floats of one job-row / pose-row buffer
+  float *Asm = gq_sm, *Bsm = gq_sm + 2 * ABUF;
+  float *cls = gq_sm + 2 * GR_BUF;                                      // [2][NJ][64] clutter scores of the jobs, by list parity and job pass
+  uint32_t *mv01 = (uint32_t *)(cls + 2 * NJ * JT * 32), *mv2c = mv01 + 2 * MP * PR;   // [2][MP * PR] records, by group parity
   float *mb = (float *)(mv2c + 2 * MP * PR);                            // [2][MP * PR][3]
   int *bcov = (int *)(mb + 2 * MP * PR * 3);                            // [2][PR]: does pose row r cover the pixel (list parity)
   int *plist = bcov + 2 * PR;                                           // [64] listed pixels (offsets inside the chunk)
-  int *ordl = plist + 64;                                               // [64] job ids of the pass
+  int *ordl = plist + 64;                                               // [NJ][64] job ids of the sweep
   if (tid < 64 && ((pmask >> tid) & 1ull)) plist[__builtin_popcountll(pmask & ((1ull << tid) - 1ull))] = tid;
   // Wave roles (two separate loops with the same barrier count, so that the register allocation is the maximum of the
   // two roles and not their sum):
   //   the first T * JT waves, the MATRIX waves: wave w multiplies job tile w / T with pose tile w % T and, every MP
   //     pixels, moves its share of the next group of records HBM -> LDS;
   //   the other T * JT waves, the STAGING waves: build the GR_PR pose rows of the next stage from the records and the
-  //     bank, and move the 64 feature rows of the stage after next HBM -> registers -> LDS.  Their loads are
-  //     unconditional and in a fixed order, so the in-order memory counter lets them wait for the bank rows (L2) without
-  //     waiting for the feature rows (HBM) issued after them.
+  //     bank (half of their fragments in each sub-stage of the current one), and move the 64 feature rows of the
+  //     sub-stage after next HBM -> registers -> LDS.  Their loads are unconditional and in a fixed order, so the in-order
+  //     memory counter lets them wait for the bank rows (L2) without waiting for the feature rows (HBM) issued after.
   const bool matrix = wave < NMW;
   const int pt = wave % T, jt = (wave / T) % JT;
   const int t2 = tid - NMW * 64, srow = t2 >> 4, sc4 = t2 & 15;              // staging waves: rows srow + SR k of a slab
@@ -443,8 +449,8 @@ __global__ __launch_bounds__(GR_NT, 4) void grid_mfma_rec_kernel(int hw, int N, 
 #define NEMO_GR_ABL 0
 #endif
   // The staging waves are the younger half of the workgroup and would lose every issue arbitration to the matrix waves
-  // of their SIMD; a static priority for them is worth 4.5 % (0.195 -> 0.186 s; priority 3 the same, priority for the
-  // matrix waves nothing -- profiles/r03_dense_grid_records.md).
+  // of their SIMD; a static priority for them is worth 3-4.5 % (priority 3 the same, priority for the matrix waves
+  // nothing -- profiles/r03_dense_grid_records.md).
 #ifndef NEMO_GR_PRIO
 #define NEMO_GR_PRIO 1
 #endif
@@ -452,7 +458,9 @@ __global__ __launch_bounds__(GR_NT, 4) void grid_mfma_rec_kernel(int hw, int N, 
   if (NEMO_GR_PRIO == 2 && !matrix) __builtin_amdgcn_s_setprio(3);
   if (NEMO_GR_PRIO == 3 && matrix) __builtin_amdgcn_s_setprio(1);
   __syncthreads();
-  for (int tg = 0; tg < ns; tg += JT * 32) {
+  for (int tg = 0; tg < ns; tg += NJ * JT * 32) {
+    const int njp = ns - tg > JT * 32 ? NJ : 1;      // job passes of this sweep (the last one may hold a single pass)
+    const int n_sub = n_stage * njp;                 // sub-stage u = (stage u / njp, job pass u % njp)
     if (matrix) {
       // records are staged MP listed pixels at a time: matrix thread t owns item t = (pose row t / MP, list slot t % MP)
       typedef float f3v __attribute__((ext_vector_type(3), aligned(4)));
@@ -474,39 +482,38 @@ __global__ __launch_bounds__(GR_NT, 4) void grid_mfma_rec_kernel(int hw, int N, 
           mb[o * 3] = mbr.x; mb[o * 3 + 1] = mbr.y; mb[o * 3 + 2] = mbr.z;
         }
       };
-      f16v lsum;
+      f16v lsum[NJ], acc[NJ];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) lsum[r] = 0.0f;
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lsum[j][r] = acc[j][r] = 0.0f;
       // ---- prologue: the records of the first group
       meta_fetch(0);
       meta_store(0);
       __syncthreads();   // the staging waves read the records
-      __syncthreads();   // ... and have written the rows of stage 0
-      f16v acc;
-#ifdef NEMO_GR_STAMP
-      unsigned long long tb_ = 0, t00_ = __builtin_readcyclecounter(), tm_ = 0;
-#endif
-      for (int s = 0; s < n_stage; ++s) {
-#ifdef NEMO_GR_STAMP
-        const unsigned long long t0_ = __builtin_readcyclecounter();
-#endif
+      __syncthreads();   // ... and have written the rows of sub-stage 0
+      // one sub-stage for job pass JP (a compile-time index: the accumulators of the two passes are separate registers)
+      auto substage = [&](const int u, const int s, auto JPc) {
+        constexpr int JP = decltype(JPc)::value;
         const int pos = s / NKS, ks = s - pos * NKS;
         if (ks == 0) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+          for (int r = 0; r < 16; ++r) acc[JP][r] = 0.0f;
         }
         // does any of this wave's 32 poses cover the pixel?  (wave-uniform; a dead tile contributes nothing)
         // So does a job tile beyond the end of a ragged pass.
-        const bool live = !(NEMO_GR_ABL & 2) && tg + jt * 32 < ns &&
+        const bool live = !(NEMO_GR_ABL & 2) && tg + JP * JT * 32 + jt * 32 < ns &&
                           __builtin_amdgcn_ballot_w64(bcov[(pos & 1) * PR + pt * 32 + i] != 0) != 0ull;
-        // records: fetched four stages, stored two stages before the staging waves first read the group
-        if ((s + 2) % GS == 0 && s + 2 < n_stage) meta_store((s + 2) / GS);
-        if ((s + 4) % GS == 0 && s + 4 < n_stage) meta_fetch((s + 4) / GS);
+        if (JP == 0) {
+          // records: fetched four stages, stored two stages before the staging waves first read the group
+          if ((s + 2) % GS == 0 && s + 2 < n_stage) meta_store((s + 2) / GS);
+          if ((s + 4) % GS == 0 && s + 4 < n_stage) meta_fetch((s + 4) / GS);
+        }
         if (live) {
-          const float *ap = gq_sm + (s & 1) * GR_BUF + (jt * 32 + i) * ROW + 4 * half;
-          const float *bp = gq_sm + (s & 1) * GR_BUF + ((JT + pt) * 32 + i) * ROW + 4 * half;
-          // one 16-byte operand step = 4 of the stage's 32 matrix instructions; the operands of the next step are read
-          // from LDS before this step's instructions are issued
+          const float *ap = Asm + (u & 1) * ABUF + (jt * 32 + i) * ROW + 4 * half;
+          const float *bp = Bsm + (s & 1) * BBUF + (pt * 32 + i) * ROW + 4 * half;
+          // one 16-byte operand step = 4 of the sub-stage's 32 matrix instructions; the operands of the next step are
+          // read from LDS before this step's instructions are issued
           f4 a0 = *(const f4 *)ap, bb = *(const f4 *)bp;
 #pragma unroll
           for (int q = 0; q < GR_KS / 8; ++q) {
@@ -514,79 +521,96 @@ __global__ __launch_bounds__(GR_NT, 4) void grid_mfma_rec_kernel(int hw, int N, 
             __builtin_amdgcn_sched_barrier(0);
             if (q + 1 < GR_KS / 8) { a0 = *(const f4 *)(ap + 8 * (q + 1)); bb = *(const f4 *)(bp + 8 * (q + 1)); }
             __builtin_amdgcn_sched_barrier(0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.x, y.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, y.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.z, y.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.w, y.w, acc, 0, 0, 0);
+            acc[JP] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.x, y.x, acc[JP], 0, 0, 0);
+            acc[JP] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, y.y, acc[JP], 0, 0, 0);
+            acc[JP] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.z, y.z, acc[JP], 0, 0, 0);
+            acc[JP] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.w, y.w, acc[JP], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
           }
           // C/D layout: column = lane & 31 (pose), row = (r & 3) + 8 * (r >> 2) + 4 * half (job of the tile)
           if (ks == NKS - 1) {
-            const float *cl_ = cls + (pos & 1) * JT * 32 + jt * 32 + 4 * half;
+            const float *cl_ = cls + ((pos & 1) * NJ + JP) * JT * 32 + jt * 32 + 4 * half;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               const f4 cv = *(const f4 *)&cl_[8 * k];
               const float cc[4] = {cv.x, cv.y, cv.z, cv.w};
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                const float o = acc[4 * k + r];
-                lsum[4 * k + r] += clutter_on ? (fmaxf(o, cc[r]) - fmaxf(0.0f, cc[r])) : o;
+                const float o = acc[JP][4 * k + r];
+                lsum[JP][4 * k + r] += clutter_on ? (fmaxf(o, cc[r]) - fmaxf(0.0f, cc[r])) : o;
               }
             }
           }
         }
-#ifdef NEMO_GR_STAMP
-        tb_ += __builtin_readcyclecounter() - t0_;
-        tm_ += live ? 1 : 0;
-#endif
-        __syncthreads();  // stage s has been consumed, stage s + 1 is in place
+      };
+      if (njp == NJ) {
+        for (int s = 0; s < n_stage; ++s) {
+          substage(2 * s, s, std::integral_constant<int, 0>{});
+          __syncthreads();  // sub-stage u has been consumed, sub-stage u + 1 is in place
+          substage(2 * s + 1, s, std::integral_constant<int, 1>{});
+          __syncthreads();
+        }
+      } else {
+        for (int s = 0; s < n_stage; ++s) {
+          substage(s, s, std::integral_constant<int, 0>{});
+          __syncthreads();
+        }
       }
-#ifdef NEMO_GR_STAMP
-      if (blockIdx.x % 977 == 5 && lane == 0 && tg == 0 && (wave == 0 || wave == 5))
-        printf("wg %d matrix wave %d: busy %llu of %llu cycles, %d stages, %llu live\n", (int)blockIdx.x, wave, tb_,
-               __builtin_readcyclecounter() - t00_, n_stage, tm_);
-#endif
       const int g = g0 + pt * 32 + i;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int jr = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (tg + jr < ns && g < G) partial[((size_t)c * N + ordl[jr]) * G + g] = lsum[r];
-      }
-    } else {
-      // ---- per-pass offsets (in 16-byte units: the feature tensor may exceed 4 GiB, its 16-byte index does not)
-      uint32_t ro[NRA];   // feature rows of the pass's jobs at pixel 0 of the chunk
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int k = 0; k < NRA; ++k) {
-        const int job = order[js + min(tg + srow + SR * k, ns - 1)];
-        ro[k] = (uint32_t)((((size_t)(img_idx ? img_idx[job] : job) * hw + p0) * D) >> 2) + (uint32_t)sc4;
-      }
+        for (int r = 0; r < 16; ++r) {
+          const int jr = j * JT * 32 + jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (tg + jr < ns && g < G) partial[((size_t)c * N + ordl[jr]) * G + g] = lsum[j][r];
+        }
+    } else {
+      // ---- per-sweep offsets (in 16-byte units: the feature tensor may exceed 4 GiB, its 16-byte index does not)
+      uint32_t ro[NJ][NRA];   // feature rows of the sweep's jobs at pixel 0 of the chunk, per job pass
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int k = 0; k < NRA; ++k) {
+          const int job = order[js + min(tg + j * JT * 32 + srow + SR * k, ns - 1)];
+          ro[j][k] = (uint32_t)((((size_t)(img_idx ? img_idx[job] : job) * hw + p0) * D) >> 2) + (uint32_t)sc4;
+        }
       // the clutter score of job t2 at the stage's pixel (threads that stage none read a valid dummy: the load below is
       // unconditional so that the memory counter's arithmetic is exact)
       const bool has_cl = clutter_on && t2 < JT * 32;
-      const float *clp = feat;
+      const float *clp[NJ] = {feat, feat};
       if (has_cl) {
-        const int job = order[js + min(tg + t2, ns - 1)];
-        clp = clu + (size_t)(img_idx ? img_idx[job] : job) * hw + p0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int job = order[js + min(tg + j * JT * 32 + t2, ns - 1)];
+          clp[j] = clu + (size_t)(img_idx ? img_idx[job] : job) * hw + p0;
+        }
       }
-      f4 st[NRA];   // the feature-row fragments of the stage after next travel through registers
+      f4 st[NRA];   // the feature-row fragments of the sub-stage after next travel through registers
       float clv = 0.0f;
-      auto fetch = [&](int s) {
+      auto fetch = [&](int u) {
+        const int s = u / njp, jp = u - s * njp;
         const int px = plist[s / NKS], ks = s % NKS;
 #pragma unroll
         for (int k = 0; k < NRA; ++k)
-          st[k] = (NEMO_GR_ABL & 8) ? f4{0.f, 0.f, 0.f, 0.f} : feat4[ro[k] + (uint32_t)(px * (D / 4) + ks * (GR_KS / 4))];
-        clv = (NEMO_GR_ABL & 8) ? 0.f : clp[has_cl ? px : 0];
+          st[k] = (NEMO_GR_ABL & 8) ? f4{0.f, 0.f, 0.f, 0.f}
+                                    : feat4[(jp ? ro[1][k] : ro[0][k]) + (uint32_t)(px * (D / 4) + ks * (GR_KS / 4))];
+        clv = (NEMO_GR_ABL & 8) ? 0.f : (jp ? clp[1] : clp[0])[has_cl ? px : 0];
       };
-      auto put_rows = [&](int s) {   // the fetched fragments of stage s go to its buffer
-        float *dst = gq_sm + (s & 1) * GR_BUF + srow * ROW + sc4 * 4;
+      auto put_rows = [&](int u) {   // the fetched fragments of sub-stage u go to its buffer
+        const int s = u / njp, jp = u - s * njp;
+        float *dst = Asm + (u & 1) * ABUF + srow * ROW + sc4 * 4;
 #pragma unroll
         for (int k = 0; k < NRA; ++k) *(f4 *)&dst[SR * k * ROW] = st[k];
-        if (s % NKS == 0 && has_cl) cls[((s / NKS) & 1) * JT * 32 + t2] = clv;
+        if (s % NKS == 0 && has_cl) cls[(((s / NKS) & 1) * NJ + jp) * JT * 32 + t2] = clv;
       };
-      // the NRB pose-row fragments of the next stage = three bank rows each, weighted by the barycentrics
-      f4 m[3][NRB];
-      float bw[3][NRB];
-      auto build_issue = [&](int s) {
+      // The pose-row fragments of this thread for stage s = three bank rows each, weighted by the barycentrics; they are
+      // built HB = NRB / 2 at a time (fragments K0 .. K0 + HB - 1), which is what is live in registers.
+      static_assert(NRB % 2 == 0, "the fragments of a stage are built in two halves");
+      constexpr int HB = NRB / 2;
+      f4 m[3][HB];
+      float bw[3][HB];
+      auto build_issue = [&](int s, auto K0c) {
+        constexpr int K0 = decltype(K0c)::value;
         const int pos = s / NKS, ks = s - pos * NKS;
         // one variable LDS index per stage; fragment k's row is a compile-time distance from it
         const int base = ((pos / MP) & 1) * MP * PR + (pos % MP) * PR + srow;
@@ -594,74 +618,83 @@ __global__ __launch_bounds__(GR_NT, 4) void grid_mfma_rec_kernel(int hw, int N, 
         const float *w_ = mb + 3 * base;
         int *c_ = bcov + (pos & 1) * PR + srow;
         const uint32_t col = (uint32_t)(ks * GR_KS + sc4 * 4);
-        uint32_t ra[NRB], rb[NRB];
+        uint32_t ra[HB], rb[HB];
 #pragma unroll
-        for (int k = 0; k < NRB; ++k) {   // every LDS read of the stage first ...
-          ra[k] = a_[SR * k]; rb[k] = b_[SR * k];
+        for (int k = 0; k < HB; ++k) {   // every LDS read first ...
+          ra[k] = a_[SR * (K0 + k)]; rb[k] = b_[SR * (K0 + k)];
 #pragma unroll
-          for (int v = 0; v < 3; ++v) bw[v][k] = w_[3 * SR * k + v];
+          for (int v = 0; v < 3; ++v) bw[v][k] = w_[3 * SR * (K0 + k) + v];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < NRB; ++k) {   // ... then the 3 NRB bank-row loads, none of them conditional: a row that does not
+        for (int k = 0; k < HB; ++k) {   // ... then the bank-row loads, none of them conditional: a row that does not
           const bool cov = (rb[k] >> 16) != 0u;   // cover the pixel reads bank row 0 with zero weights (records hold 0, 0, 0)
           const uint32_t vv[3] = {ra[k] & 0xffffu, ra[k] >> 16, rb[k] & 0xffffu};
 #pragma unroll
           for (int v = 0; v < 3; ++v) {
             m[v][k] = (NEMO_GR_ABL & 1) ? f4{0.f, 0.f, 0.f, 0.f} : *(gf4p)(bank + (vv[v] * (uint32_t)D + col));
           }
-          if (ks == 0 && sc4 == 0) c_[SR * k] = cov ? 1 : 0;
+          if (ks == 0 && sc4 == 0) c_[SR * (K0 + k)] = cov ? 1 : 0;
         }
       };
-      auto build_put = [&](int s) {
-        float *dst = gq_sm + (s & 1) * GR_BUF + (JT * 32 + srow) * ROW + sc4 * 4;
+      auto build_put = [&](int s, auto K0c) {
+        constexpr int K0 = decltype(K0c)::value;
+        float *dst = Bsm + (s & 1) * BBUF + srow * ROW + sc4 * 4;
 #pragma unroll
-        for (int k = 0; k < NRB; ++k)   // (b0 * r0 + b1 * r1) + b2 * r2: interpolate_kernel's arithmetic
-          *(f4 *)&dst[SR * k * ROW] = (bw[0][k] * m[0][k] + bw[1][k] * m[1][k]) + bw[2][k] * m[2][k];
+        for (int k = 0; k < HB; ++k)   // (b0 * r0 + b1 * r1) + b2 * r2: interpolate_kernel's arithmetic
+          *(f4 *)&dst[SR * (K0 + k) * ROW] = (bw[0][k] * m[0][k] + bw[1][k] * m[1][k]) + bw[2][k] * m[2][k];
       };
-      // ---- prologue: the job ids of the pass, the feature rows of stages 0 and 1, the pose rows of stage 0
-      if (t2 < JT * 32) ordl[t2] = order[js + min(tg + t2, ns - 1)];
+      using I0 = std::integral_constant<int, 0>;
+      using IH = std::integral_constant<int, HB>;
+      // one sub-stage of the staging side: half K0 of the next stage's pose rows (both halves when the sweep has a single
+      // job pass), the job rows of sub-stage u + 1 into LDS, those of sub-stage u + 2 into registers
+      auto stage_sub = [&](int u, int s, auto K0c, bool both) {
+        if (s + 1 < n_stage && !(NEMO_GR_ABL & 4)) {   // ONE conditional around the whole sequence: every wait count is exact
+          build_issue(s + 1, K0c);                       // bank-row loads (L2)
+          __builtin_amdgcn_sched_barrier(0);
+          put_rows(min(u + 1, n_sub - 1));               // the NRA + 1 loads issued one sub-stage ago
+          __builtin_amdgcn_sched_barrier(0);
+          fetch(min(u + 2, n_sub - 1));                  // NRA + 1 loads (HBM), younger than the bank rows build_put waits for
+          __builtin_amdgcn_sched_barrier(0);
+          build_put(s + 1, K0c);
+          if (both) {
+            __builtin_amdgcn_sched_barrier(0);
+            build_issue(s + 1, IH{});
+            __builtin_amdgcn_sched_barrier(0);
+            build_put(s + 1, IH{});
+          }
+        } else {
+          put_rows(min(u + 1, n_sub - 1));               // (the last stage: nothing left to build)
+          __builtin_amdgcn_sched_barrier(0);
+          fetch(min(u + 2, n_sub - 1));
+        }
+      };
+      // ---- prologue: the job ids of the sweep, the feature rows of sub-stages 0 and 1, the pose rows of stage 0
+      if (t2 < NJ * JT * 32) ordl[t2] = order[js + min(tg + t2, ns - 1)];
       fetch(0);
       put_rows(0);
-      fetch(min(1, n_stage - 1));
+      fetch(min(1, n_sub - 1));
       __syncthreads();   // the records of the first group are in LDS
-      build_issue(0);
-      build_put(0);
+      build_issue(0, I0{});
+      build_put(0, I0{});
+      build_issue(0, IH{});
+      build_put(0, IH{});
       __syncthreads();
-#ifdef NEMO_GR_STAMP
-      unsigned long long tb_ = 0, t00_ = __builtin_readcyclecounter(), tw_ = 0;
-#endif
-      for (int s = 0; s < n_stage; ++s) {
-#ifdef NEMO_GR_STAMP
-        const unsigned long long t0_ = __builtin_readcyclecounter();
-#endif
-        if (s + 1 < n_stage && !(NEMO_GR_ABL & 4)) {
-          build_issue(s + 1);                    // 3 NRB loads (L2)
-          __builtin_amdgcn_sched_barrier(0);
-          put_rows(s + 1);                       // the NRA + 1 loads issued one stage ago
-          __builtin_amdgcn_sched_barrier(0);
-          fetch(min(s + 2, n_stage - 1));        // NRA + 1 loads (HBM), younger than the bank rows build_put waits for
-          __builtin_amdgcn_sched_barrier(0);
-#ifdef NEMO_GR_STAMP
-          const unsigned long long t1_ = __builtin_readcyclecounter();
-#endif
-          build_put(s + 1);
-#ifdef NEMO_GR_STAMP
-          tw_ += __builtin_readcyclecounter() - t1_;
-#endif
+      if (njp == NJ) {
+        for (int s = 0; s < n_stage; ++s) {
+          stage_sub(2 * s, s, I0{}, false);
+          __syncthreads();
+          stage_sub(2 * s + 1, s, IH{}, false);
+          __syncthreads();
         }
-#ifdef NEMO_GR_STAMP
-        tb_ += __builtin_readcyclecounter() - t0_;
-#endif
-        __syncthreads();
+      } else {
+        for (int s = 0; s < n_stage; ++s) {
+          stage_sub(s, s, I0{}, true);
+          __syncthreads();
+        }
       }
-#ifdef NEMO_GR_STAMP
-      if (blockIdx.x % 977 == 5 && lane == 0 && tg == 0 && (wave == 8 || wave == 13))
-        printf("wg %d staging wave %d: busy %llu of %llu cycles (build_put incl. its wait %llu), %d stages\n", (int)blockIdx.x, wave,
-               tb_, __builtin_readcyclecounter() - t00_, tw_, n_stage);
-#endif
     }
-    __syncthreads();  // the next pass restages the LDS
+    __syncthreads();  // the next sweep restages the LDS
   }
 }
 

@@ -715,9 +715,9 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
   // from which grid_mfma_rec_kernel builds the rendered rows on the fly.  Rendered here in slices of poses through a
   // temporary pix_to_face / bary buffer (campos -> rasterize -> pack).  Ordinary (LDS-table) meshes only.
   // Chosen when the dense renders of all G poses exceed the budget and the records do not (measured, BASELINE config 4:
-  // 12 classes x 9720 poses, 0.221 s against 0.453 s for block-after-block rendering), and for grids of 4096 poses or
-  // more even when the renders would fit (one class x 9720 poses: 0.186 s and 1.6 GB against 0.196 s and 40 GB; at 144
-  // poses the renders are the faster operand, 4.5 against 7.7 ms) -- profiles/r03_dense_grid_records.md.
+  // 12 classes x 9720 poses, 0.194 s against 0.455 s for block-after-block rendering), and for grids of 4096 poses or
+  // more even when the renders would fit (one class x 9720 poses: 0.141 s and 1.6 GB against 0.198 s and 40 GB; at 144
+  // poses the two are within 0.2 ms of each other and the renders stay the default) -- profiles/r03_dense_grid_records.md.
   const double map_budget = ctx->env_prerender_map_gb * 1073741824.0;
   const bool maps_fit = (double)n_pairs * G * stride * ctx->cfg.feat_dim * 4.0 <= map_budget;
   if (n_pairs <= GP_MAX_PAIRS && !ctx->P.big && !ctx->env_grid_no_mfma && (double)n_pairs * G * stride * 20.0 <= map_budget &&
