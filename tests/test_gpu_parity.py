@@ -1384,6 +1384,32 @@ def test_dense_grid_record_store_ragged(oracle, monkeypatch):
         assert np.abs(losses[k] - lo).max() <= REL * np.abs(lo).max() and best[k] == bo
 
 
+def test_large_grid_takes_the_record_store_by_default(monkeypatch):
+    """nemo_grid_prerender's default choice: a grid of 4096 poses or more is kept as records even though its dense
+    renders would fit the budget (the record-based search is the faster one there); the losses are those of the dense
+    renders bit for bit, whichever way the store orders its poses."""
+    from nemo_amd.engine import PoseEngine
+    sc = make_scene('car', (256, 384), 200, n_img=3, seed=17)
+    gC, gth = syn.pose_grid(sc.distance, n_azim=36, n_elev=6, n_theta=4, distances=tuple(sc.distance * x for x in (0.8, 0.9, 1.0, 1.1, 1.2)))
+    assert len(gth) == 4320
+    dC, dth = _dev(gC[None]), _dev(gth[None])
+    feats, clus = _dev(sc.feats), _dev(sc.clus)
+    out = {}
+    for mode, env in (('default', {}), ('maps', {'NEMO_GRID_RECORDS': '0'}), ('grid_order', {'NEMO_GRID_GROUP': '0'})):
+        for k in ('NEMO_GRID_RECORDS', 'NEMO_GRID_GROUP', 'NEMO_PRERENDER_MAP_GB'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = PoseEngine(sc.geo.S, (sc.geo.h, sc.geo.w), sc.D)
+        eng.register_mesh(sc.verts, sc.faces, sc.bank)
+        eng.grid_prerender(dC, dth, [(0, 0)])
+        assert eng.grid_store_kind() == ('dense_maps' if mode == 'maps' else 'records')
+        out[mode] = eng.grid_search(feats, clus, dC, dth)
+    for mode in ('default', 'grid_order'):
+        assert torch.equal(out[mode][3], out['maps'][3]) and torch.equal(out[mode][2], out['maps'][2])
+    assert torch.isfinite(out['default'][3]).all()
+
+
 def test_large_mesh_256d_double_resolution(oracle):
     """BASELINE config 5 shape: subdivided cuboid (10 466 vertices, 19 872 faces), 256-d features, 160x200
     window of a 200x200 raster, clutter loss.  The mesh tables do not fit the LDS, so the kernels run in their
