@@ -1384,6 +1384,52 @@ def test_dense_grid_record_store_ragged(oracle, monkeypatch):
         assert np.abs(losses[k] - lo).max() <= REL * np.abs(lo).max() and best[k] == bo
 
 
+@pytest.mark.parametrize('seed', [0, 1, 2, 3, 4, 5])
+def test_record_store_random_shapes_equal_dense_renders(monkeypatch, seed):
+    """Seeded random shapes for the record-based grid search: 1-3 stored pairs with their own grids, a random number of
+    poses (not a multiple of the 32-pose tile or the 64-pose block, sometimes below either), random jobs per pair --
+    none, a few, more than one 128-job sweep, exactly 64 / 65 --, random image and pair per job, 128-d and 256-d, with
+    and without the clutter term.  The losses and the argmin must equal those of the dense renders bit for bit."""
+    from nemo_amd.engine import PoseEngine
+    rng = np.random.default_rng(1000 + seed)
+    D = 256 if seed % 3 == 2 else 128
+    clutter = seed % 2 == 0
+    n_pairs = int(rng.integers(1, 4))
+    scenes = [make_scene(['car', 'bus', 'bottle'][k], (256, 320), int(rng.integers(80, 260)), n_img=2, seed=300 + 10 * seed + k,
+                         D=D, clutter=clutter) for k in range(n_pairs)]
+    na, ne, nt = int(rng.integers(2, 9)), int(rng.integers(1, 5)), int(rng.integers(1, 4))
+    grids = [syn.pose_grid(sc.distance, n_azim=na, n_elev=ne, n_theta=nt) for sc in scenes]
+    G = len(grids[0][1])
+    counts = [int(rng.choice([0, 1, 5, 64, 65, 130, 200])) for _ in range(n_pairs)]
+    if sum(counts) == 0:
+        counts[0] = 3
+    pair_of = np.concatenate([np.full(c, k, np.int32) for k, c in enumerate(counts)])
+    rng.shuffle(pair_of)
+    img_of = (2 * pair_of + rng.integers(0, 2, len(pair_of))).astype(np.int32)
+    dC, dth = _dev(np.stack([g[0] for g in grids])), _dev(np.stack([g[1] for g in grids]))
+    feats = _dev(np.concatenate([sc.feats for sc in scenes]))
+    clus = _dev(np.concatenate([sc.clus for sc in scenes])) if clutter else None
+    out = {}
+    for mode in ('maps', 'records', 'grid_order'):
+        for k in ('NEMO_GRID_RECORDS', 'NEMO_GRID_GROUP'):
+            monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv('NEMO_GRID_RECORDS', '0' if mode == 'maps' else '1')
+        if mode == 'grid_order':
+            monkeypatch.setenv('NEMO_GRID_GROUP', '0')
+        sc0 = scenes[0]
+        eng = PoseEngine(sc0.geo.S, (sc0.geo.h, sc0.geo.w), D, clutter=clutter)
+        for sc in scenes:
+            eng.register_mesh(sc.verts, sc.faces, sc.bank)
+        eng.grid_prerender(dC, dth, [(k, k) for k in range(n_pairs)])
+        assert eng.grid_store_kind() == ('dense_maps' if mode == 'maps' else 'records')
+        out[mode] = eng.grid_search(feats, clus, dC, dth, img_idx=_dev(img_of, torch.int32), mesh_idx=_dev(pair_of, torch.int32),
+                                    grid_idx=_dev(pair_of, torch.int32))
+    assert out['maps'][3].shape == (len(pair_of), G) and torch.isfinite(out['maps'][3]).all()
+    for mode in ('records', 'grid_order'):
+        assert torch.equal(out[mode][3], out['maps'][3]), (mode, G, counts, D, clutter)
+        assert torch.equal(out[mode][2], out['maps'][2])
+
+
 def test_large_grid_takes_the_record_store_by_default(monkeypatch):
     """nemo_grid_prerender's default choice: a grid of 4096 poses or more is kept as records even though its dense
     renders would fit the budget (the record-based search is the faster one there); the losses are those of the dense
