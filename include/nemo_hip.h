@@ -195,6 +195,20 @@ int nemo_solve(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t
                const float *d_feat, const float *d_clu, const float *d_C0, const float *d_theta0,
                float *d_pose, float *d_loss, float *d_trace, int32_t *d_status, void *stream);
 
+/* How nemo_solve / nemo_solve6 / nemo_solve_static spend their time -- the two forms give the same poses up to the
+ * summation order inside a dot product (both are checked against the oracle to the same 1e-4):
+ *  - TABLES (default when they fit): the object score needs, per covered pixel, the dot products of the pixel's feature
+ *    row with the three bank rows of its face.  None of that depends on the pose, so the call first computes ALL
+ *    feature-row x bank-row products of every job on the matrix cores (f32 [job][V][win_h*win_w], 35 MB per job at
+ *    V = 1088 and an 80 x 100 window) and its Adam steps read three floats per covered pixel.  The tables live in the
+ *    workspace sized by nemo_workspace_reserve(ctx, max_jobs, ...): max_jobs x (largest registered mesh) x window x 4
+ *    bytes, allocated only when that is within NEMO_SOLVE_TABLE_GB (environment, read at nemo_ctx_create; default 64,
+ *    0 = never).  A call uses them when its N jobs fit the reservation; never for meshes whose tables do not fit the LDS.
+ *  - STREAMING (otherwise): every Adam step reads the covered pixels' feature rows (4*D + 4 bytes per covered pixel and
+ *    step) and contracts them with the bank rows in the kernel.
+ * nemo_solve_table_capacity: the number of jobs the reserved tables hold for the meshes registered so far (0: streaming). */
+int64_t nemo_solve_table_capacity(const nemo_ctx *ctx);
+
 /* 6-DoF variant of the solve (code/PredUnlabeledDataset.py:318-347): Adam also moves trans_2d, which
  * enters the camera as extra_trans = trans_2d @ [[1,0,0],[0,1,0]] added to T (:328, lib/MeshUtils.py:107-108).
  * Same kernel as nemo_solve.  d_trans0 f32[N][2] (NULL = zeros, :318); d_pose6 f32[N][6] =

@@ -11,10 +11,15 @@ namespace {
 // RAW = true: `feat` holds an upstream gradient dL/d(out) [h][w][D] of the
 // interpolated map and the routine back-propagates it (module path); otherwise
 // `feat` is the image feature map and the loss of MeshPoseSolveAll.py:58-59 is used.
-template <int D, bool PERSP, bool GRAD, bool SCORE, bool RAW = false, bool PRE = false, bool BIG = false, bool TAIL_SYNC = true>
+// TAB (solve kernel only): `tab` = this job's table of ALL feature-row x bank-row dot products, f32 [V][h * w]
+// (bank_table_kernel).  The three dot products of a covered pixel are then three 4-byte reads instead of a 512-byte
+// feature row, three bank rows and 3 D multiply-adds: the contraction does not depend on the pose, so it is done once
+// per solve instead of once per Adam step.
+template <int D, bool PERSP, bool GRAD, bool SCORE, bool RAW = false, bool PRE = false, bool BIG = false, bool TAIL_SYNC = true,
+          bool TAB = false>
 __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, const float *__restrict__ feat,
                           const float *__restrict__ clu, EmitOut emit, bool zb_clean = false,
-                          const float *__restrict__ vpre = nullptr) {
+                          const float *__restrict__ vpre = nullptr, const float *__restrict__ tab = nullptr) {
 #ifndef NEMO_KIT
 #define NEMO_KIT 2
 #endif
@@ -161,6 +166,112 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       float GR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       float GT[3] = {0.f, 0.f, 0.f};
       int cb = seg_b;
+      // ---------------- phase B for one list entry: its 13 contributions (g0, g1, g2 = the pixel's feature row against the
+      // face's three bank rows, by vertex slot)
+      auto phase_b = [&](const uint32_t ent_b, const float cl, const float g0, const float g1, const float g2) {
+          const int p = (int)(ent_b & 0xffffu), f = (int)(ent_b >> 16);
+          const int pi = (int)__umulhi((unsigned)p, P.w_magic), pj = p - pi * P.w;
+          const int a = S - 1 - (pj + P.c0), b = S - 1 - (pi + P.r0);
+          const us4 fv_ = fc_at<BIG>(L, f);
+          const int i0 = fv_.x, i1 = fv_.y, i2 = fv_.z;
+          float v[9];
+          load_face_verts<BIG>(L, i0, i1, i2, v);
+          const float px = L.ndc[a], py = L.ndc[b];
+          // coverage was decided (exactly) by the rasterizer; the quantities below only feed the
+          // 1e-4-tolerance loss and gradient, so reciprocals replace IEEE divisions here
+          const float ia = __builtin_amdgcn_rcpf(face_area_eps(v, P.keps));
+          const float w0 = edge_fn(px, py, v[3], v[4], v[6], v[7]) * ia;
+          const float w1 = edge_fn(px, py, v[6], v[7], v[0], v[1]) * ia;
+          const float w2 = edge_fn(px, py, v[0], v[1], v[3], v[4]) * ia;
+          float b0 = w0, b1 = w1, b2 = w2, iden = 1.0f;
+          if (PERSP) {
+            const float t0 = (w0 * v[5]) * v[8], t1 = (v[2] * w1) * v[8], t2 = (v[2] * v[5]) * w2;
+            iden = __builtin_amdgcn_rcpf((t0 + t1) + t2);
+            b0 = t0 * iden; b1 = t1 * iden; b2 = t2 * iden;
+          }
+          const float obj = (b0 * g0 + b1 * g1) + b2 * g2;
+          float ind;
+          if (RAW) {
+            ind = 1.0f;
+          } else if (P.clutter) {
+            pl += fmaxf(obj, cl) - fmaxf(0.0f, cl);
+            ind = obj > cl ? 1.0f : (obj == cl ? 0.5f : 0.0f);
+          } else {
+            pl += obj;
+            ind = 1.0f;
+          }
+          if (GRAD && ind != 0.0f) {
+            const float up = RAW ? 1.0f : -P.inv_hw * ind;
+            const float gb0 = up * g0, gb1 = up * g1, gb2 = up * g2;
+            float gw0 = gb0, gw1 = gb1, gw2 = gb2, gz0 = 0.f, gz1 = 0.f, gz2 = 0.f;
+            if (PERSP) {
+              const float z0 = v[2], z1 = v[5], z2 = v[8];
+              const float dot = (gb0 * b0 + gb1 * b1) + gb2 * b2;
+              const float gt0 = (gb0 - dot) * iden, gt1 = (gb1 - dot) * iden, gt2 = (gb2 - dot) * iden;
+              gw0 = gt0 * z1 * z2; gw1 = gt1 * z0 * z2; gw2 = gt2 * z0 * z1;
+              gz0 = gt1 * w1 * z2 + gt2 * z1 * w2;
+              gz1 = gt0 * w0 * z2 + gt2 * z0 * w2;
+              gz2 = gt0 * w0 * z1 + gt1 * z0 * w1;
+            }
+            const float gE0 = gw0 * ia, gE1 = gw1 * ia, gE2 = gw2 * ia;
+            const float gA = -((gw0 * w0 + gw1 * w1) + gw2 * w2) * ia;
+            float gv[9];
+            gv[0] = gE1 * (v[7] - py) + gE2 * (py - v[4]) + gA * (v[7] - v[4]);
+            gv[1] = gE1 * (px - v[6]) + gE2 * (v[3] - px) + gA * (v[3] - v[6]);
+            gv[2] = gz0;
+            gv[3] = gE0 * (py - v[7]) + gE2 * (v[1] - py) + gA * (v[1] - v[7]);
+            gv[4] = gE0 * (v[6] - px) + gE2 * (px - v[0]) + gA * (v[6] - v[0]);
+            gv[5] = gz1;
+            gv[6] = gE0 * (v[4] - py) + gE1 * (py - v[1]) + gA * (v[4] - v[1]);
+            gv[7] = gE0 * (px - v[3]) + gE1 * (v[0] - px) + gA * (v[0] - v[3]);
+            gv[8] = gz2;
+            const int vi[3] = {i0, i1, i2};
+            const float inv_s = 1.0f / s, T0 = L.ust[U_T], T1 = L.ust[U_T + 1], T2 = L.ust[U_T + 2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const float iz = __builtin_amdgcn_rcpf(v[3 * c + 2]);
+              const float gxc = gv[3 * c] * iz, gyc = gv[3 * c + 1] * iz;
+              const float gzv = gv[3 * c + 2] - (gv[3 * c] * v[3 * c] + gv[3 * c + 1] * v[3 * c + 1]) * iz;
+              const float q0 = s * gxc, q1 = s * gyc, q2 = gzv;
+              // world vertex = (view - T) R^T: accumulate against (view - T) and rotate the 3x3 total once
+              // at the end (no world-space vertex table in LDS)
+              const float zs = v[3 * c + 2] * inv_s;
+              const float X0 = v[3 * c] * zs - T0, X1 = v[3 * c + 1] * zs - T1, X2 = v[3 * c + 2] - T2;
+              (void)vi;
+              GR[0] = fmaf(X0, q0, GR[0]); GR[1] = fmaf(X0, q1, GR[1]); GR[2] = fmaf(X0, q2, GR[2]);
+              GR[3] = fmaf(X1, q0, GR[3]); GR[4] = fmaf(X1, q1, GR[4]); GR[5] = fmaf(X1, q2, GR[5]);
+              GR[6] = fmaf(X2, q0, GR[6]); GR[7] = fmaf(X2, q1, GR[7]); GR[8] = fmaf(X2, q2, GR[8]);
+              GT[0] += q0; GT[1] += q1; GT[2] += q2;
+            }
+          }
+      };
+      if constexpr (TAB) {
+        // The dot products come from the job's table: one lane per entry, the entry's list word, clutter score and three
+        // table values are fetched one chunk ahead (unconditionally, with a clamped index: exact wait counts).
+        const gf32p gtab = as_global(tab);
+        const uint32_t hw32 = (uint32_t)(P.h * P.w);
+        uint32_t ent_c = 0u;
+        float cl_c = 0.f, g_c[3] = {0.f, 0.f, 0.f};
+        auto fetch = [&](int cb_, uint32_t &ent, float &cl, float (&g)[3]) {
+          const int e_ = min(cb_ + lane, max(seg_e - 1, seg_b));
+          ent = L.list[min(e_, max(ntot - 1, 0))];
+          const uint32_t px = ent & 0xffffu;
+          cl = (P.clutter && clu) ? gclu[px] : 0.0f;
+          const us4 fv_ = fc_at<BIG>(L, ent >> 16);
+          g[0] = gtab[(uint32_t)fv_.x * hw32 + px]; g[1] = gtab[(uint32_t)fv_.y * hw32 + px]; g[2] = gtab[(uint32_t)fv_.z * hw32 + px];
+        };
+        if (cb < seg_e) fetch(cb, ent_c, cl_c, g_c);
+        while (cb < seg_e) {
+          const int cn = min(CH, seg_e - cb);
+          uint32_t ent_n;
+          float cl_n, g_n[3];
+          fetch(cb + CH, ent_n, cl_n, g_n);
+          if (lane < cn) phase_b(ent_c, cl_c, g_c[0], g_c[1], g_c[2]);
+          ent_c = ent_n; cl_c = cl_n; g_c[0] = g_n[0]; g_c[1] = g_n[1]; g_c[2] = g_n[2];
+          cb += CH;
+        }
+      }
+      if constexpr (!TAB) {
 #if NEMO_PHASEA_MFMA
       // wave-private scratch in the (dead) z-buffer region, WS_BYTES per wave: per-entry words, per-tile run tables,
       // the phase A -> B hand-off buffer and a dump row for the lanes that have nothing to hand off
@@ -392,89 +503,13 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
 #pragma unroll
         for (int u = 0; u < CH / 64; ++u)
         if (u * 64 + lane < cn) {
-          const uint32_t ent_b = ent_bs[u];
-          const float cl = cls[u];
           const int lb = u * 64 + lane;
-          const int p = (int)(ent_b & 0xffffu), f = (int)(ent_b >> 16);
-          const int pi = (int)__umulhi((unsigned)p, P.w_magic), pj = p - pi * P.w;
-          const int a = S - 1 - (pj + P.c0), b = S - 1 - (pi + P.r0);
-          const us4 fv_ = fc_at<BIG>(L, f);
-          const int i0 = fv_.x, i1 = fv_.y, i2 = fv_.z;
-          const float g0 = gbuf[3 * lb], g1 = gbuf[3 * lb + 1], g2 = gbuf[3 * lb + 2];
-          float v[9];
-          load_face_verts<BIG>(L, i0, i1, i2, v);
-          const float px = L.ndc[a], py = L.ndc[b];
-          // coverage was decided (exactly) by the rasterizer; the quantities below only feed the
-          // 1e-4-tolerance loss and gradient, so reciprocals replace IEEE divisions here
-          const float ia = __builtin_amdgcn_rcpf(face_area_eps(v, P.keps));
-          const float w0 = edge_fn(px, py, v[3], v[4], v[6], v[7]) * ia;
-          const float w1 = edge_fn(px, py, v[6], v[7], v[0], v[1]) * ia;
-          const float w2 = edge_fn(px, py, v[0], v[1], v[3], v[4]) * ia;
-          float b0 = w0, b1 = w1, b2 = w2, iden = 1.0f;
-          if (PERSP) {
-            const float t0 = (w0 * v[5]) * v[8], t1 = (v[2] * w1) * v[8], t2 = (v[2] * v[5]) * w2;
-            iden = __builtin_amdgcn_rcpf((t0 + t1) + t2);
-            b0 = t0 * iden; b1 = t1 * iden; b2 = t2 * iden;
-          }
-          const float obj = (b0 * g0 + b1 * g1) + b2 * g2;
-          float ind;
-          if (RAW) {
-            ind = 1.0f;
-          } else if (P.clutter) {
-            pl += fmaxf(obj, cl) - fmaxf(0.0f, cl);
-            ind = obj > cl ? 1.0f : (obj == cl ? 0.5f : 0.0f);
-          } else {
-            pl += obj;
-            ind = 1.0f;
-          }
-          if (GRAD && ind != 0.0f) {
-            const float up = RAW ? 1.0f : -P.inv_hw * ind;
-            const float gb0 = up * g0, gb1 = up * g1, gb2 = up * g2;
-            float gw0 = gb0, gw1 = gb1, gw2 = gb2, gz0 = 0.f, gz1 = 0.f, gz2 = 0.f;
-            if (PERSP) {
-              const float z0 = v[2], z1 = v[5], z2 = v[8];
-              const float dot = (gb0 * b0 + gb1 * b1) + gb2 * b2;
-              const float gt0 = (gb0 - dot) * iden, gt1 = (gb1 - dot) * iden, gt2 = (gb2 - dot) * iden;
-              gw0 = gt0 * z1 * z2; gw1 = gt1 * z0 * z2; gw2 = gt2 * z0 * z1;
-              gz0 = gt1 * w1 * z2 + gt2 * z1 * w2;
-              gz1 = gt0 * w0 * z2 + gt2 * z0 * w2;
-              gz2 = gt0 * w0 * z1 + gt1 * z0 * w1;
-            }
-            const float gE0 = gw0 * ia, gE1 = gw1 * ia, gE2 = gw2 * ia;
-            const float gA = -((gw0 * w0 + gw1 * w1) + gw2 * w2) * ia;
-            float gv[9];
-            gv[0] = gE1 * (v[7] - py) + gE2 * (py - v[4]) + gA * (v[7] - v[4]);
-            gv[1] = gE1 * (px - v[6]) + gE2 * (v[3] - px) + gA * (v[3] - v[6]);
-            gv[2] = gz0;
-            gv[3] = gE0 * (py - v[7]) + gE2 * (v[1] - py) + gA * (v[1] - v[7]);
-            gv[4] = gE0 * (v[6] - px) + gE2 * (px - v[0]) + gA * (v[6] - v[0]);
-            gv[5] = gz1;
-            gv[6] = gE0 * (v[4] - py) + gE1 * (py - v[1]) + gA * (v[4] - v[1]);
-            gv[7] = gE0 * (px - v[3]) + gE1 * (v[0] - px) + gA * (v[0] - v[3]);
-            gv[8] = gz2;
-            const int vi[3] = {i0, i1, i2};
-            const float inv_s = 1.0f / s, T0 = L.ust[U_T], T1 = L.ust[U_T + 1], T2 = L.ust[U_T + 2];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              const float iz = __builtin_amdgcn_rcpf(v[3 * c + 2]);
-              const float gxc = gv[3 * c] * iz, gyc = gv[3 * c + 1] * iz;
-              const float gzv = gv[3 * c + 2] - (gv[3 * c] * v[3 * c] + gv[3 * c + 1] * v[3 * c + 1]) * iz;
-              const float q0 = s * gxc, q1 = s * gyc, q2 = gzv;
-              // world vertex = (view - T) R^T: accumulate against (view - T) and rotate the 3x3 total once
-              // at the end (no world-space vertex table in LDS)
-              const float zs = v[3 * c + 2] * inv_s;
-              const float X0 = v[3 * c] * zs - T0, X1 = v[3 * c + 1] * zs - T1, X2 = v[3 * c + 2] - T2;
-              (void)vi;
-              GR[0] = fmaf(X0, q0, GR[0]); GR[1] = fmaf(X0, q1, GR[1]); GR[2] = fmaf(X0, q2, GR[2]);
-              GR[3] = fmaf(X1, q0, GR[3]); GR[4] = fmaf(X1, q1, GR[4]); GR[5] = fmaf(X1, q2, GR[5]);
-              GR[6] = fmaf(X2, q0, GR[6]); GR[7] = fmaf(X2, q1, GR[7]); GR[8] = fmaf(X2, q2, GR[8]);
-              GT[0] += q0; GT[1] += q1; GT[2] += q2;
-            }
-          }
+          phase_b(ent_bs[u], cls[u], gbuf[3 * lb], gbuf[3 * lb + 1], gbuf[3 * lb + 2]);
         }
         STAMP(9);
         cb = cb_next;
       }
+      }  // !TAB
       {  // the wave's partials (fixed DPP tree), left in L.red by one lane
         float pv[13];
         pv[0] = wave_sum_dpp(pl);

@@ -1010,6 +1010,132 @@ __global__ __launch_bounds__(CkCfg<D>::NT) void clutter_kernel(const float *__re
   }
 }
 
+// Per-job table of ALL feature-row x bank-row dot products: tab[n][v][p] = <bank_m(n)[v], feat_img(n)[p]>, f32
+// [N][tab_stride / hw rows][hw].  The three dot products the solve needs per covered pixel and Adam step do not depend
+// on the pose, so nemo_solve computes them once here -- a [V x D] . [D x hw] product per job on the fp32 matrix cores,
+// clutter_kernel's structure with the accumulators stored instead of maximised -- and its 300 steps read three floats
+// per covered pixel (eval_pose<TAB>).  Vertex-major rows: a lane owns a pixel column, so a stored accumulator row is 32
+// consecutive pixels (128 bytes), and the pixels of a face and of its neighbours share the table's cache lines.
+// Grid: (workgroups per job, N).
+template <int D>
+__global__ __launch_bounds__(CkCfg<D>::NT) void bank_table_kernel(const float *__restrict__ feat, int hw,
+                                                                  const int32_t *img_idx, const int32_t *mesh_idx,
+                                                                  const MeshDesc *meshes, float *__restrict__ tab,
+                                                                  size_t tab_stride) {
+  constexpr int NT = CkCfg<D>::NT, NWV = NT / 64;
+  constexpr int RS = D + 4;                       // padded row stride in floats
+  constexpr int NS = CK_ROWS * (D / 4) / NT;      // 16-byte pieces of a chunk per thread
+  extern __shared__ __align__(16) float cl[];     // [2][CK_ROWS][RS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, half = lane >> 5;
+  const int n = blockIdx.y;
+  const MeshDesc M = meshes[mesh_idx ? mesh_idx[n] : 0];
+  const int K = M.V;
+  const float *cbank = M.bank;
+  const float *fimg = feat + (size_t)(img_idx ? img_idx[n] : n) * hw * D;
+  __attribute__((address_space(1))) float *gout = (__attribute__((address_space(1))) float *)(tab + (size_t)n * tab_stride);
+  const int nchunks = (K + CK_ROWS - 1) / CK_ROWS;
+  const int ntiles = (hw + 31) / 32;
+  f4 st[NS];
+  auto stage_load = [&](int c) {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      const int idx = tid + j * NT, row = idx / (D / 4), col4 = idx - row * (D / 4);
+      st[j] = ((const f4 *)cbank)[(size_t)min(c * CK_ROWS + row, K - 1) * (D / 4) + col4];
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      const int idx = tid + j * NT, row = idx / (D / 4), col4 = idx - row * (D / 4);
+      *(f4 *)(cl + (size_t)buf * CK_ROWS * RS + row * RS + 4 * col4) = st[j];
+    }
+  };
+  auto load_x = [&](int tile, f4(&x)[D / 8]) {
+    const int pix = min(tile * 32 + i, hw - 1);
+    const f4 *xp = (const f4 *)(fimg + (size_t)pix * D) + half;
+#pragma unroll
+    for (int q = 0; q < D / 8; ++q) x[q] = __builtin_nontemporal_load(xp + 2 * q);
+  };
+  const int stride = (int)gridDim.x * NWV;
+  int base = (int)blockIdx.x * NWV;  // the workgroup's first tile of the round; every wave takes part in every round
+  if (base >= ntiles) return;         // (barriers), waves past the end recompute the last tile and write nothing
+  f4 xc[D / 8];   // the tile's 32 feature rows; the next tile's are fetched at the end of a round (one exposed load
+  stage_load(0);  // latency per 17-chunk round; a second register set would spill the accumulators' store addresses)
+  load_x(min(base + wave, ntiles - 1), xc);
+  stage_store(0);
+  __syncthreads();
+  int buf = 0;
+  auto round = [&]() {
+    const int tile = base + wave;
+    const int nbase = base + stride;
+    const int p = tile * 32 + i;
+    const bool pok = tile < ntiles && p < hw;
+    for (int c = 0; c < nchunks; ++c) {
+      if (nchunks > 1) stage_load(c + 1 == nchunks ? 0 : c + 1);
+      const float *ap = cl + (size_t)buf * CK_ROWS * RS + i * RS + 4 * half;
+      // rows i and 32 + i of the chunk against the tile's 32 pixels; the A operands are read one step ahead of the
+      // matrix instructions that use them
+      f16v acc0, acc1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+      f4 e0, e1, o0, o1;
+      e0 = *(const f4 *)(ap);
+      e1 = *(const f4 *)(ap + 32 * RS);
+      auto mm = [&](const f4 &a0, const f4 &a1, const f4 &xv) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, xv.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, xv.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, xv.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, xv.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, xv.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, xv.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, xv.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, xv.w, acc1, 0, 0, 0);
+      };
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < D / 8; q += 2) {
+        o0 = *(const f4 *)(ap + 8 * (q + 1));
+        o1 = *(const f4 *)(ap + 32 * RS + 8 * (q + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        mm(e0, e1, xc[q]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (q + 2 < D / 8) {
+          e0 = *(const f4 *)(ap + 8 * (q + 2));
+          e1 = *(const f4 *)(ap + 32 * RS + 8 * (q + 2));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mm(o0, o1, xc[q + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // C/D layout: column = lane & 31 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * half (bank row of the 32-row tile)
+      if (pok) {   // a job's table is far below 4 GiB: 32-bit offsets from one base
+        const uint32_t uhw = (uint32_t)hw;
+        const int vb = c * CK_ROWS + 4 * half;
+        uint32_t off = (uint32_t)vb * uhw + (uint32_t)p;
+#pragma unroll
+        for (int r8 = 0; r8 < 4; ++r8) {
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const int v0 = vb + r4 + 8 * r8;
+            if (v0 < K) gout[off + (uint32_t)r4 * uhw] = acc0[4 * r8 + r4];
+            if (v0 + 32 < K) gout[off + (uint32_t)(r4 + 32) * uhw] = acc1[4 * r8 + r4];
+          }
+          off += 8u * uhw;
+        }
+      }
+      if (nchunks > 1) {
+        stage_store(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+      }
+    }
+    if (nbase < ntiles) load_x(min(nbase + wave, ntiles - 1), xc);
+    base = nbase;
+  };
+  while (base < ntiles) round();
+}
+
 // Clutter score for a small bank (K <= 8; the reference's mean clutter vector is K = 1, code/MeshPoseSolveAll.py:207):
 // a matrix-core tile would be all padding, and the pass is a pure stream of the feature maps.  D/8 lanes per pixel
 // read the pixel's row as two coalesced 16-byte loads per lane (all rows of a wave's 8 iterations in flight at once),

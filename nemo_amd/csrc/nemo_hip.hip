@@ -22,6 +22,7 @@
 // explicit fmaf.  Reference citations (file:line) are into Angtian/NeMo.
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <mutex>
 #include <vector>
 #include <math.h>
@@ -84,6 +85,11 @@ struct nemo_ctx {
   int n_cu;              // its compute-unit count (cached: hipGetDeviceProperties is slow)
   // environment switches, read ONCE in nemo_ctx_create (hot calls never call getenv)
   int env_grid_no_mfma, env_solve_stagger, env_solve_order, env_solve_affinity, env_slot_identity;
+  // nemo_solve's per-job tables of feature-row x bank-row dot products (bank_table_kernel): sized by
+  // nemo_workspace_reserve for max_jobs jobs when that fits NEMO_SOLVE_TABLE_GB (default 64; 0 = never)
+  float *d_tab;
+  size_t tab_cap;            // floats
+  double env_solve_table_gb;
   int env_grid_records;  // NEMO_GRID_RECORDS: -1 (default) the record store when the dense renders do not fit or G >= 4096; 0 never; 1 whenever it fits
   double env_prerender_map_gb;
   char err[512];
@@ -318,6 +324,8 @@ int nemo_ctx_create(const nemo_config *cfg, nemo_ctx **out) {
   SET_LDS_B(grid_kernel, 256, false); SET_LDS_B(grid_kernel, 256, true);
   SET_LDS_B(solve_kernel, 128, false); SET_LDS_B(solve_kernel, 128, true);
   SET_LDS_B(solve_kernel, 256, false); SET_LDS_B(solve_kernel, 256, true);
+  SET_LDS((solve_kernel<128, false, false, true>)); SET_LDS((solve_kernel<128, true, false, true>));
+  SET_LDS((solve_kernel<256, false, false, true>)); SET_LDS((solve_kernel<256, true, false, true>));
   SET_LDS_B(interp_bwd_kernel, 128, false); SET_LDS_B(interp_bwd_kernel, 128, true);
   SET_LDS_B(interp_bwd_kernel, 256, false); SET_LDS_B(interp_bwd_kernel, 256, true);
 #undef SET_LDS_B
@@ -326,6 +334,8 @@ int nemo_ctx_create(const nemo_config *cfg, nemo_ctx **out) {
   hipFuncSetAttribute((const void *)grid_mfma_rec_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GR_LDS);
   hipFuncSetAttribute((const void *)feature_head_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
   hipFuncSetAttribute((const void *)feature_head_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  hipFuncSetAttribute((const void *)bank_table_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CK_ROWS * (128 + 4) * 4);
+  hipFuncSetAttribute((const void *)bank_table_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CK_ROWS * (256 + 4) * 4);
   hipFuncSetAttribute((const void *)clutter_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CK_ROWS * (128 + 4) * 4);
   hipFuncSetAttribute((const void *)clutter_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CK_ROWS * (256 + 4) * 4);
   // device facts and environment switches are read here, once; hot calls never query either
@@ -338,6 +348,10 @@ int nemo_ctx_create(const nemo_config *cfg, nemo_ctx **out) {
   auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
   ctx->env_grid_no_mfma = env_int("NEMO_GRID_NO_MFMA", 0);
   ctx->env_solve_stagger = env_int("NEMO_SOLVE_STAGGER", 0);
+  {
+    const char *e_ = getenv("NEMO_SOLVE_TABLE_GB");
+    ctx->env_solve_table_gb = e_ ? atof(e_) : 64.0;
+  }
   ctx->env_solve_order = env_int("NEMO_SOLVE_ORDER", 1);
   ctx->env_solve_affinity = env_int("NEMO_SOLVE_AFFINITY", 1);
   ctx->env_slot_identity = env_int("NEMO_SLOT_ORDER", 1) == 0;
@@ -386,6 +400,20 @@ int nemo_workspace_reserve(nemo_ctx *ctx, int32_t max_jobs, int32_t max_grid_pos
     HIP_TRY(ctx, hipMalloc(&ctx->d_gs_partial, sizeof(float) * need_partial));
     ctx->gs_partial_cap = need_partial;
   }
+  // the solve's dot-product tables: max_jobs x (largest registered mesh, at least 2048 vertices' worth of headroom is NOT
+  // kept: a mesh registered later with more vertices than fit makes the solve fall back to streaming the feature rows)
+  {
+    const size_t hw = (size_t)ctx->cfg.win_h * ctx->cfg.win_w;
+    const size_t vrows = (size_t)(ctx->vmax_seen > 0 ? ctx->vmax_seen : 0);
+    const size_t need = N * vrows * hw;
+    if (!ctx->P.big && vrows > 0 && need > ctx->tab_cap && (double)need * 4.0 <= ctx->env_solve_table_gb * 1073741824.0) {
+      hipFree(ctx->d_tab);
+      ctx->d_tab = nullptr;
+      ctx->tab_cap = 0;
+      HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tab, sizeof(float) * need));
+      ctx->tab_cap = need;
+    }
+  }
   // large meshes: one table slice per workgroup of the widest launch (per-job kernels: N; grid search: sliced)
   size_t blocks = N;
   if (G > 0) {
@@ -412,7 +440,7 @@ int nemo_ctx_destroy(nemo_ctx *ctx) {
   hipFree(ctx->d_pre_slot); hipFree(ctx->d_pre_cnt); hipFree(ctx->d_pre_pairs); hipFree(ctx->d_pre_list);
   hipFree(ctx->d_pre_vid); hipFree(ctx->d_pre_bary); hipFree(ctx->d_pre_mask); hipFree(ctx->d_pre_perm); hipFree(ctx->d_pre_slotof);
   hipFree(ctx->d_pre_maps); hipFree(ctx->d_gs_order); hipFree(ctx->d_gs_start); hipFree(ctx->d_gs_jobslot);
-  hipFree(ctx->d_gs_partial); hipFree(ctx->d_gs_work); hipFree(ctx->d_big); hipFree(ctx->d_so);
+  hipFree(ctx->d_gs_partial); hipFree(ctx->d_gs_work); hipFree(ctx->d_big); hipFree(ctx->d_so); hipFree(ctx->d_tab);
   for (int i = 0; i < ctx->n_meshes; ++i) hipFree(ctx->d_slot_order[i]);
   delete ctx;
   return NEMO_OK;
@@ -835,6 +863,12 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
   return NEMO_OK;
 }
 
+int64_t nemo_solve_table_capacity(const nemo_ctx *ctx) {
+  if (!ctx || !ctx->d_tab || ctx->P.big || ctx->vmax_seen <= 0) return 0;
+  const size_t stride = (size_t)ctx->vmax_seen * (size_t)ctx->cfg.win_h * ctx->cfg.win_w;
+  return (int64_t)(ctx->tab_cap / stride);
+}
+
 int nemo_grid_store_kind(const nemo_ctx *ctx) {
   if (!ctx) return 0;
   if (ctx->d_pre_vid) return 3;
@@ -877,9 +911,34 @@ static int launch_solve(nemo_ctx *ctx, const char *who, int32_t N, const int32_t
     }
     d_order = d_ord;
   }
+  // Tables of feature-row x bank-row dot products, when the reserved workspace holds them for this call: the contraction
+  // is done once here instead of once per Adam step.  Same poses up to the summation order of a dot
+  // product; never for large (BIG) meshes.
+  const size_t hw = (size_t)ctx->cfg.win_h * ctx->cfg.win_w, tab_stride = (size_t)ctx->vmax_seen * hw;
+  if (!ctx->P.big && ctx->d_tab && (size_t)N * tab_stride <= ctx->tab_cap && tab_stride > 0) {
+    const int D = ctx->cfg.feat_dim, nt = D == 128 ? CkCfg<128>::NT : CkCfg<256>::NT;
+    const size_t lds = (size_t)2 * CK_ROWS * (D + 4) * 4;
+    const unsigned wpj = (unsigned)std::min<size_t>(8, ((hw + 31) / 32 + (nt / 64) - 1) / (nt / 64));
+    if (D == 128)
+      hipLaunchKernelGGL((bank_table_kernel<128>), dim3(wpj, (unsigned)N), dim3(nt), lds, (hipStream_t)stream, d_feat, (int)hw,
+                         d_img_idx, d_mesh_idx, (const MeshDesc *)ctx->d_meshes, ctx->d_tab, tab_stride);
+    else
+      hipLaunchKernelGGL((bank_table_kernel<256>), dim3(wpj, (unsigned)N), dim3(nt), lds, (hipStream_t)stream, d_feat, (int)hw,
+                         d_img_idx, d_mesh_idx, (const MeshDesc *)ctx->d_meshes, ctx->d_tab, tab_stride);
+#define SOLVE_TAB(DD, PP)                                                                                                   \
+  hipLaunchKernelGGL((solve_kernel<DD, PP, false, true>), dim3(N), dim3(NT), ctx->lds, (hipStream_t)stream, ctx->P,         \
+                     ctx->d_meshes, d_img_idx, d_mesh_idx, d_feat, d_clu, d_C0, d_theta0, d_trans0, ndof, ctx->d_adam,       \
+                     ctx->adam_steps, ctx->beta1, ctx->beta2, ctx->eps, d_pose, d_loss, d_trace, ctx->d_counter, stagger,   \
+                     d_order, (int)N, d_status, (const float *)ctx->d_tab, tab_stride)
+    if (D == 128) { if (ctx->P.persp) SOLVE_TAB(128, true); else SOLVE_TAB(128, false); }
+    else          { if (ctx->P.persp) SOLVE_TAB(256, true); else SOLVE_TAB(256, false); }
+#undef SOLVE_TAB
+    HIP_TRY(ctx, hipGetLastError());
+    return NEMO_OK;
+  }
   DISPATCH_DP(solve_kernel, dim3(N), ctx->P, ctx->d_meshes, d_img_idx, d_mesh_idx, d_feat, d_clu, d_C0, d_theta0, d_trans0,
               ndof, ctx->d_adam, ctx->adam_steps, ctx->beta1, ctx->beta2, ctx->eps, d_pose, d_loss, d_trace, ctx->d_counter,
-              stagger, d_order, (int)N, d_status);
+              stagger, d_order, (int)N, d_status, (const float *)nullptr, (size_t)0);
   HIP_TRY(ctx, hipGetLastError());
   return NEMO_OK;
 }

@@ -277,14 +277,17 @@ __global__ void solve_affinity_kernel(int N, int n_meshes, const int32_t *mesh_i
 // The fused solve: code/MeshPoseSolveAll.py:227-250 in one launch.  Thread 0
 // runs the serial part of every step (camera, camera backward, Adam) and hands
 // R, T to the workgroup through LDS; (C, theta) and the Adam moments live in LDS.
-template <int D, bool PERSP, bool BIG>
+// TAB: the per-job tables of feature-row x bank-row dot products exist (bank_table_kernel, launched just before);
+// job n's table is tab + n * tab_stride floats.
+template <int D, bool PERSP, bool BIG, bool TAB = false>
 __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc *meshes, const int32_t *img_idx,
                                                       const int32_t *mesh_idx, const float *feat, const float *clu,
                                                       const float *C0, const float *theta0, const float *trans0,
                                                       int ndof, const float *adam_tab, int steps, float beta1,
                                                       float beta2, float eps, float *pose, float *loss_out,
                                                       float *trace, u64 *counter, int stagger,
-                                                      const int32_t *order, int N, int32_t *status) {
+                                                      const int32_t *order, int N, int32_t *status,
+                                                      const float *tab = nullptr, size_t tab_stride = 0) {
   const int n = order ? order[blockIdx.x] : (int)blockIdx.x;  // longest job first (solve_order_kernel)
   // `order` is a permutation of [0, N) written by this call's own set-up kernels; a workgroup that reads anything
   // else (nemo_solve_static's shared array overwritten by an overlapping call) leaves instead of indexing with it
@@ -349,7 +352,8 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
   for (int t = 0; t < steps; ++t) {
     // no closing barrier inside: thread 0 leaves eval_pose with the totals and goes straight on to Adam, the other
     // waves clear the z-buffer meanwhile (the score loop's scratch in that region is dead behind the band barrier)
-    eval_pose<D, PERSP, true, true, false, false, BIG, false>(P, L, M, f, c, none, true, vreg);
+    eval_pose<D, PERSP, true, true, false, false, BIG, false, TAB>(P, L, M, f, c, none, true, vreg,
+                                                                     TAB ? tab + (size_t)n * tab_stride : nullptr);
     fetch_verts();
     for (int i = threadIdx.x; i < P.cap; i += NT) L.zb[i] = ~0ull;
 #ifdef NEMO_STAMPS

@@ -307,6 +307,13 @@ class PoseEngine:
                    'nemo_grid_prerender')
         self._pre_keep = (grid_C, grid_theta)  # the store is keyed by these device buffers: keep them alive
 
+    def solve_table_capacity(self):
+        """Jobs per call the reserved dot-product tables hold (nemo_solve_table_capacity); 0 = the solve streams."""
+        return int(self.lib.nemo_solve_table_capacity(self.ctx))
+
+    def solve_uses_tables(self, n_jobs=1):
+        return self.solve_table_capacity() >= max(1, int(n_jobs))
+
     GRID_STORE_KINDS = ('none', 'dense_maps', 'pose_blocks', 'records')
 
     def grid_store_kind(self):
