@@ -1016,24 +1016,26 @@ __global__ __launch_bounds__(CkCfg<D>::NT) void clutter_kernel(const float *__re
 // clutter_kernel's structure with the accumulators stored instead of maximised -- and its 300 steps read three floats
 // per covered pixel (eval_pose<TAB>).  Vertex-major rows: a lane owns a pixel column, so a stored accumulator row is 32
 // consecutive pixels (128 bytes), and the pixels of a face and of its neighbours share the table's cache lines.
-// Grid: (workgroups per job, N).
+// Grid: (workgroups per job, jobs of the launch); slot y of the table belongs to the job workgroup y of the solve runs.
 template <int D>
 __global__ __launch_bounds__(CkCfg<D>::NT) void bank_table_kernel(const float *__restrict__ feat, int hw,
                                                                   const int32_t *img_idx, const int32_t *mesh_idx,
                                                                   const MeshDesc *meshes, float *__restrict__ tab,
-                                                                  size_t tab_stride) {
+                                                                  size_t tab_stride, const int32_t *order, int N) {
   constexpr int NT = CkCfg<D>::NT, NWV = NT / 64;
   constexpr int RS = D + 4;                       // padded row stride in floats
   constexpr int NS = CK_ROWS * (D / 4) / NT;      // 16-byte pieces of a chunk per thread
   extern __shared__ __align__(16) float cl[];     // [2][CK_ROWS][RS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, half = lane >> 5;
-  const int n = blockIdx.y;
+  // table slot blockIdx.y holds the job the solve's workgroup blockIdx.y will run: order[blockIdx.y], or blockIdx.y itself
+  const int n = order ? order[blockIdx.y] : (int)blockIdx.y;
+  if ((unsigned)n >= (unsigned)N) return;   // (nemo_solve_static's shared order array overwritten by an overlapping call)
   const MeshDesc M = meshes[mesh_idx ? mesh_idx[n] : 0];
   const int K = M.V;
   const float *cbank = M.bank;
   const float *fimg = feat + (size_t)(img_idx ? img_idx[n] : n) * hw * D;
-  __attribute__((address_space(1))) float *gout = (__attribute__((address_space(1))) float *)(tab + (size_t)n * tab_stride);
+  __attribute__((address_space(1))) float *gout = (__attribute__((address_space(1))) float *)(tab + (size_t)blockIdx.y * tab_stride);
   const int nchunks = (K + CK_ROWS - 1) / CK_ROWS;
   const int ntiles = (hw + 31) / 32;
   f4 st[NS];

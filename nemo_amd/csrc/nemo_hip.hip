@@ -400,18 +400,23 @@ int nemo_workspace_reserve(nemo_ctx *ctx, int32_t max_jobs, int32_t max_grid_pos
     HIP_TRY(ctx, hipMalloc(&ctx->d_gs_partial, sizeof(float) * need_partial));
     ctx->gs_partial_cap = need_partial;
   }
-  // the solve's dot-product tables: max_jobs x (largest registered mesh, at least 2048 vertices' worth of headroom is NOT
-  // kept: a mesh registered later with more vertices than fit makes the solve fall back to streaming the feature rows)
+  // the solve's dot-product tables: as many jobs as fit NEMO_SOLVE_TABLE_GB, at most max_jobs (a call with more jobs goes
+  // through in slices of that many; under 256 jobs' worth -- one per CU -- the solve streams the feature rows instead)
   {
     const size_t hw = (size_t)ctx->cfg.win_h * ctx->cfg.win_w;
-    const size_t vrows = (size_t)(ctx->vmax_seen > 0 ? ctx->vmax_seen : 0);
-    const size_t need = N * vrows * hw;
-    if (!ctx->P.big && vrows > 0 && need > ctx->tab_cap && (double)need * 4.0 <= ctx->env_solve_table_gb * 1073741824.0) {
-      hipFree(ctx->d_tab);
-      ctx->d_tab = nullptr;
-      ctx->tab_cap = 0;
-      HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tab, sizeof(float) * need));
-      ctx->tab_cap = need;
+    const size_t stride = (size_t)(ctx->vmax_seen > 0 ? ctx->vmax_seen : 0) * hw;
+    if (!ctx->P.big && stride > 0 && N > 0) {
+      size_t jobs = (size_t)(ctx->env_solve_table_gb * 1073741824.0 / ((double)stride * 4.0));
+      if (jobs > N) jobs = N;
+      if (jobs < N && jobs < 256) jobs = 0;
+      if (jobs * stride > ctx->tab_cap) {
+        hipFree(ctx->d_tab);
+        ctx->d_tab = nullptr;
+        ctx->tab_cap = 0;
+        // not getting the tables is not an error: the solve then streams the feature rows
+        if (hipMalloc((void **)&ctx->d_tab, sizeof(float) * jobs * stride) == hipSuccess) ctx->tab_cap = jobs * stride;
+        else { ctx->d_tab = nullptr; (void)hipGetLastError(); }
+      }
     }
   }
   // large meshes: one table slice per workgroup of the widest launch (per-job kernels: N; grid search: sliced)
@@ -911,28 +916,34 @@ static int launch_solve(nemo_ctx *ctx, const char *who, int32_t N, const int32_t
     }
     d_order = d_ord;
   }
-  // Tables of feature-row x bank-row dot products, when the reserved workspace holds them for this call: the contraction
-  // is done once here instead of once per Adam step.  Same poses up to the summation order of a dot
-  // product; never for large (BIG) meshes.
+  // Tables of feature-row x bank-row dot products, when the reserved workspace holds them: the contraction is done once
+  // here instead of once per Adam step.  Same poses up to the summation order of a dot product; never for
+  // large (BIG) meshes.  A call with more jobs than the tables hold goes through in slices of the launch order (which
+  // then exists: such a call has more than 64 jobs): tables for a slice, then its solve, on the one stream.
   const size_t hw = (size_t)ctx->cfg.win_h * ctx->cfg.win_w, tab_stride = (size_t)ctx->vmax_seen * hw;
-  if (!ctx->P.big && ctx->d_tab && (size_t)N * tab_stride <= ctx->tab_cap && tab_stride > 0) {
+  const size_t tab_jobs = (!ctx->P.big && ctx->d_tab && tab_stride > 0) ? ctx->tab_cap / tab_stride : 0;
+  if (tab_jobs >= (size_t)N || (tab_jobs >= 256 && d_order)) {
     const int D = ctx->cfg.feat_dim, nt = D == 128 ? CkCfg<128>::NT : CkCfg<256>::NT;
     const size_t lds = (size_t)2 * CK_ROWS * (D + 4) * 4;
     const unsigned wpj = (unsigned)std::min<size_t>(8, ((hw + 31) / 32 + (nt / 64) - 1) / (nt / 64));
-    if (D == 128)
-      hipLaunchKernelGGL((bank_table_kernel<128>), dim3(wpj, (unsigned)N), dim3(nt), lds, (hipStream_t)stream, d_feat, (int)hw,
-                         d_img_idx, d_mesh_idx, (const MeshDesc *)ctx->d_meshes, ctx->d_tab, tab_stride);
-    else
-      hipLaunchKernelGGL((bank_table_kernel<256>), dim3(wpj, (unsigned)N), dim3(nt), lds, (hipStream_t)stream, d_feat, (int)hw,
-                         d_img_idx, d_mesh_idx, (const MeshDesc *)ctx->d_meshes, ctx->d_tab, tab_stride);
+    for (size_t k0 = 0; k0 < (size_t)N; k0 += tab_jobs) {
+      const unsigned nk = (unsigned)std::min<size_t>(tab_jobs, (size_t)N - k0);
+      const int32_t *ord = d_order ? d_order + k0 : nullptr;   // (no order: a single slice, slot y = job y)
+      if (D == 128)
+        hipLaunchKernelGGL((bank_table_kernel<128>), dim3(wpj, nk), dim3(nt), lds, (hipStream_t)stream, d_feat, (int)hw,
+                           d_img_idx, d_mesh_idx, (const MeshDesc *)ctx->d_meshes, ctx->d_tab, tab_stride, ord, (int)N);
+      else
+        hipLaunchKernelGGL((bank_table_kernel<256>), dim3(wpj, nk), dim3(nt), lds, (hipStream_t)stream, d_feat, (int)hw,
+                           d_img_idx, d_mesh_idx, (const MeshDesc *)ctx->d_meshes, ctx->d_tab, tab_stride, ord, (int)N);
 #define SOLVE_TAB(DD, PP)                                                                                                   \
-  hipLaunchKernelGGL((solve_kernel<DD, PP, false, true>), dim3(N), dim3(NT), ctx->lds, (hipStream_t)stream, ctx->P,         \
+  hipLaunchKernelGGL((solve_kernel<DD, PP, false, true>), dim3(nk), dim3(NT), ctx->lds, (hipStream_t)stream, ctx->P,        \
                      ctx->d_meshes, d_img_idx, d_mesh_idx, d_feat, d_clu, d_C0, d_theta0, d_trans0, ndof, ctx->d_adam,       \
                      ctx->adam_steps, ctx->beta1, ctx->beta2, ctx->eps, d_pose, d_loss, d_trace, ctx->d_counter, stagger,   \
-                     d_order, (int)N, d_status, (const float *)ctx->d_tab, tab_stride)
-    if (D == 128) { if (ctx->P.persp) SOLVE_TAB(128, true); else SOLVE_TAB(128, false); }
-    else          { if (ctx->P.persp) SOLVE_TAB(256, true); else SOLVE_TAB(256, false); }
+                     ord, (int)N, d_status, (const float *)ctx->d_tab, tab_stride)
+      if (D == 128) { if (ctx->P.persp) SOLVE_TAB(128, true); else SOLVE_TAB(128, false); }
+      else          { if (ctx->P.persp) SOLVE_TAB(256, true); else SOLVE_TAB(256, false); }
 #undef SOLVE_TAB
+    }
     HIP_TRY(ctx, hipGetLastError());
     return NEMO_OK;
   }

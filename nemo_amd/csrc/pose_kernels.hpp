@@ -278,7 +278,7 @@ __global__ void solve_affinity_kernel(int N, int n_meshes, const int32_t *mesh_i
 // runs the serial part of every step (camera, camera backward, Adam) and hands
 // R, T to the workgroup through LDS; (C, theta) and the Adam moments live in LDS.
 // TAB: the per-job tables of feature-row x bank-row dot products exist (bank_table_kernel, launched just before);
-// job n's table is tab + n * tab_stride floats.
+// the table of this workgroup's job is slot blockIdx.x: tab + blockIdx.x * tab_stride floats.
 template <int D, bool PERSP, bool BIG, bool TAB = false>
 __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc *meshes, const int32_t *img_idx,
                                                       const int32_t *mesh_idx, const float *feat, const float *clu,
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
     // no closing barrier inside: thread 0 leaves eval_pose with the totals and goes straight on to Adam, the other
     // waves clear the z-buffer meanwhile (the score loop's scratch in that region is dead behind the band barrier)
     eval_pose<D, PERSP, true, true, false, false, BIG, false, TAB>(P, L, M, f, c, none, true, vreg,
-                                                                     TAB ? tab + (size_t)n * tab_stride : nullptr);
+                                                                     TAB ? tab + (size_t)blockIdx.x * tab_stride : nullptr);
     fetch_verts();
     for (int i = threadIdx.x; i < P.cap; i += NT) L.zb[i] = ~0ull;
 #ifdef NEMO_STAMPS

@@ -580,7 +580,8 @@ def test_hot_calls_do_not_allocate():
     assert rc == -3 and b'nemo_workspace_reserve' in eng.lib.nemo_last_error(eng.ctx)
     rc = eng.lib.nemo_grid_search(eng.ctx, n, p(idx), p(mesh), p(mesh), p(wl.feats), p(clu), p(s.grid_C), p(s.grid_theta), 144,
                                   p(losses), p(pose), p(loss), None, eng._stream())
-    assert rc == -3 and held() == base
+    # (the HIP runtime may grow its own pools by a few MB at any call; a workspace grown for 200 jobs would take far more)
+    assert rc == -3 and held() <= base + (32 << 20)
 
 
 def test_non_finite_job_is_flagged_not_fatal():
@@ -1438,6 +1439,48 @@ def test_record_store_random_shapes_equal_dense_renders(monkeypatch, seed):
     for mode in ('records', 'grid_order'):
         assert torch.equal(out[mode][3], out['maps'][3]), (mode, G, counts, D, clutter)
         assert torch.equal(out[mode][2], out['maps'][2])
+
+
+@pytest.mark.parametrize('D,persp', [(128, False), (128, True), (256, False)])
+def test_solve_tables_against_streaming(oracle, monkeypatch, D, persp):
+    """The two forms of the fused solve on the same jobs: per-job dot-product tables (matrix cores, once per call)
+    against feature rows streamed every step.  Same start, so the first iterates agree to rounding; loss and gradient
+    of the table form at traced iterates against the oracle (teacher-forced); more jobs than the tables hold go through
+    in slices of the launch order and give the same bits as one slice."""
+    from nemo_amd.engine import PoseEngine
+    sc = make_scene('car', (256, 384), 300, n_img=3, seed=29, D=D, perspective_correct=persp)
+    rng = np.random.default_rng(5)
+    n = 300
+    img = rng.integers(0, 3, n).astype(np.int32)
+    az, el, th, ds = (np.asarray([sc.gt[i][k] for i in img]) for k in range(4))
+    C0 = syn.spherical_to_campos(ds * rng.uniform(0.95, 1.05, n), el + rng.normal(0, 0.05, n), az + rng.normal(0, 0.08, n))
+    th0 = (th + rng.normal(0, 0.04, n)).astype(np.float32)
+    feats, clus = _dev(sc.feats), _dev(sc.clus)
+    out = {}
+    stride_gb = sc.verts.shape[0] * sc.cfg.h * sc.cfg.w * 4 / 2 ** 30      # one job's table
+    for mode, gb in (('tables', None), ('streaming', '0'), ('sliced', '%.6f' % (260 * stride_gb))):
+        if gb is None:
+            monkeypatch.delenv('NEMO_SOLVE_TABLE_GB', raising=False)
+        else:
+            monkeypatch.setenv('NEMO_SOLVE_TABLE_GB', gb)
+        eng = PoseEngine(sc.geo.S, (sc.geo.h, sc.geo.w), D, perspective_correct=persp)
+        eng.register_mesh(sc.verts, sc.faces, sc.bank)
+        eng.set_schedule(40)
+        pose, loss, tr = eng.solve(feats, clus, _dev(C0), _dev(th0), img_idx=_dev(img, torch.int32), want_trace=True)
+        cap = eng.solve_table_capacity()
+        assert (cap >= n) if mode == 'tables' else (cap == 0) if mode == 'streaming' else (256 <= cap < n)
+        out[mode] = (pose.cpu().numpy(), loss.cpu().numpy(), tr.cpu().numpy())
+    assert np.array_equal(out['sliced'][0], out['tables'][0]) and np.array_equal(out['sliced'][2], out['tables'][2])
+    tt, ts = out['tables'][2], out['streaming'][2]
+    # (C, theta) of the first iterates: Adam's first steps are lr * g / (|g| + eps) per component, which turns the last
+    # bits of a small gradient component into ~1e-5 of the parameter
+    assert np.abs(tt[:, :3, :4] - ts[:, :3, :4]).max() < 1e-4
+    assert _relerr(tt[:, 0, 4], ts[:, 0, 4]) < 1e-5                     # loss at the common start
+    for j in (0, 7, 123, 299):
+        for t in (0, 20, 39):
+            e = oracle.evaluate(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[img[j]], sc.clus[img[j]], tt[j, t, 0:3], tt[j, t, 3])
+            assert abs(tt[j, t, 4] - e['loss']) <= REL * abs(e['loss'])
+            assert _relerr(tt[j, t, 5:9], np.r_[e['gC'], e['gtheta']]) <= REL
 
 
 def test_large_grid_takes_the_record_store_by_default(monkeypatch):
