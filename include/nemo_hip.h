@@ -208,6 +208,10 @@ int nemo_solve(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t
  *    step) and contracts them with the bank rows in the kernel.
  * nemo_solve_table_capacity: the number of jobs the reserved tables hold for the meshes registered so far (0: streaming). */
 int64_t nemo_solve_table_capacity(const nemo_ctx *ctx);
+/* Measurement aid, no counterpart in the reference: device time of the two kernels of the last TABLES-form solve call of
+ * this context (its first slice) -- bank_table_kernel and solve_kernel -- from events the call records on its stream.
+ * SYNCHRONISES on the last of them.  NEMO_ERR_STATE if the last solve streamed. */
+int nemo_solve_last_timing(nemo_ctx *ctx, float *table_ms, float *loop_ms);
 
 /* 6-DoF variant of the solve (code/PredUnlabeledDataset.py:318-347): Adam also moves trans_2d, which
  * enters the camera as extra_trans = trans_2d @ [[1,0,0],[0,1,0]] added to T (:328, lib/MeshUtils.py:107-108).

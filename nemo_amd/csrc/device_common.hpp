@@ -23,7 +23,12 @@ constexpr int U_P6 = 84, U_M6 = 86, U_V6 = 88;  // 6-DoF variant: trans_2d and i
 // block totals: [0] loss term, [1..9] dL/dR, [10..12] dL/dT, [13] covered pixels
 constexpr int T_LOSS = 0, T_GR = 1, T_GT = 10, T_NCOV = 13;
 constexpr int MAX_MESHES = 1024;
-constexpr int LDS_BUDGET = 160 * 1024 / (1024 / NT) - (NT < 1024 ? 512 : 0);  // the workgroups resident on a CU share its 160 KiB
+#ifdef NEMO_STAMPS
+constexpr int STAMP_LDS = 512;  // the diagnostic build's static stamp counters come out of the dynamic budget
+#else
+constexpr int STAMP_LDS = 0;
+#endif
+constexpr int LDS_BUDGET = 160 * 1024 / (1024 / NT) - (NT < 1024 ? 512 : 0) - STAMP_LDS;  // the workgroups resident on a CU share its 160 KiB
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
@@ -334,12 +339,24 @@ __device__ __forceinline__ int wave_scan_incl(int v, int lane) {
 #ifdef NEMO_STAMPS
 __device__ unsigned long long g_stamps[16];
 __device__ unsigned long long g_wave_busy[16];  // score-loop busy time by wave index
+// The stamps are summed in LDS (slots 0..15 = phases, 16..31 = score-loop busy time by wave) and flushed to the global
+// counters once per workgroup (stamp_flush, end of solve_kernel): a global atomic per phase and step from 256 resident
+// workgroups onto 16 addresses costs more than the shorter phases last.
+__device__ __forceinline__ unsigned long long *stamp_lds() {
+  __shared__ unsigned long long s_[32];
+  return s_;
+}
+__device__ __forceinline__ void stamp_zero() { if (threadIdx.x < 32) stamp_lds()[threadIdx.x] = 0ull; }
+__device__ __forceinline__ void stamp_flush() {
+  if (threadIdx.x < 16) atomicAdd(&g_stamps[threadIdx.x], stamp_lds()[threadIdx.x]);
+  else if (threadIdx.x < 32) atomicAdd(&g_wave_busy[threadIdx.x - 16], stamp_lds()[threadIdx.x]);
+}
 #define STAMP_DECL unsigned long long st_prev = (threadIdx.x == 0) ? __builtin_amdgcn_s_memrealtime() : 0ull
 #define STAMP(i)                                                         \
   do {                                                                   \
     if (threadIdx.x == 0) {                                              \
       const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();      \
-      atomicAdd(&g_stamps[i], now_ - st_prev);                           \
+      stamp_lds()[i] += now_ - st_prev;                                  \
       st_prev = now_;                                                    \
     }                                                                    \
   } while (0)

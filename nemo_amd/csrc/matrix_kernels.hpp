@@ -1120,8 +1120,16 @@ __global__ __launch_bounds__(CkCfg<D>::NT) void bank_table_kernel(const float *_
 #pragma unroll
           for (int r4 = 0; r4 < 4; ++r4) {
             const int v0 = vb + r4 + 8 * r8;
-            if (v0 < K) gout[off + (uint32_t)r4 * uhw] = acc0[4 * r8 + r4];
-            if (v0 + 32 < K) gout[off + (uint32_t)(r4 + 32) * uhw] = acc1[4 * r8 + r4];
+#ifndef NEMO_TAB_NT
+#define NEMO_TAB_NT 1
+#endif
+            if (NEMO_TAB_NT) {
+              if (v0 < K) __builtin_nontemporal_store(acc0[4 * r8 + r4], gout + (off + (uint32_t)r4 * uhw));
+              if (v0 + 32 < K) __builtin_nontemporal_store(acc1[4 * r8 + r4], gout + (off + (uint32_t)(r4 + 32) * uhw));
+            } else {
+              if (v0 < K) gout[off + (uint32_t)r4 * uhw] = acc0[4 * r8 + r4];
+              if (v0 + 32 < K) gout[off + (uint32_t)(r4 + 32) * uhw] = acc1[4 * r8 + r4];
+            }
           }
           off += 8u * uhw;
         }

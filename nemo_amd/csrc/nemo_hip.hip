@@ -90,6 +90,8 @@ struct nemo_ctx {
   float *d_tab;
   size_t tab_cap;            // floats
   double env_solve_table_gb;
+  hipEvent_t ev_solve[3];    // recorded around the table kernel and the solve kernel of the last table-form call (first slice)
+  int ev_solve_valid;
   int env_grid_records;  // NEMO_GRID_RECORDS: -1 (default) the record store when the dense renders do not fit or G >= 4096; 0 never; 1 whenever it fits
   double env_prerender_map_gb;
   char err[512];
@@ -304,6 +306,7 @@ int nemo_ctx_create(const nemo_config *cfg, nemo_ctx **out) {
   if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_counter, sizeof(u64));
   if (e == hipSuccess) e = hipMemset(ctx->d_counter, 0, sizeof(u64));
   ctx->adam_cap = 4096;
+  for (int i = 0; i < 3; ++i) if (e == hipSuccess) e = hipEventCreate(&ctx->ev_solve[i]);
   if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_adam, sizeof(float) * 2 * ctx->adam_cap);
   if (e != hipSuccess) {
     int code = hip_fail(nullptr, e, "nemo_ctx_create: hipMalloc");
@@ -447,6 +450,7 @@ int nemo_ctx_destroy(nemo_ctx *ctx) {
   hipFree(ctx->d_pre_maps); hipFree(ctx->d_gs_order); hipFree(ctx->d_gs_start); hipFree(ctx->d_gs_jobslot);
   hipFree(ctx->d_gs_partial); hipFree(ctx->d_gs_work); hipFree(ctx->d_big); hipFree(ctx->d_so); hipFree(ctx->d_tab);
   for (int i = 0; i < ctx->n_meshes; ++i) hipFree(ctx->d_slot_order[i]);
+  for (int i = 0; i < 3; ++i) if (ctx->ev_solve[i]) hipEventDestroy(ctx->ev_solve[i]);
   delete ctx;
   return NEMO_OK;
 }
@@ -868,6 +872,15 @@ int nemo_grid_prerender(nemo_ctx *ctx, const float *d_grid_C, const float *d_gri
   return NEMO_OK;
 }
 
+int nemo_solve_last_timing(nemo_ctx *ctx, float *table_ms, float *loop_ms) {
+  if (!ctx || !table_ms || !loop_ms) return fail(ctx, NEMO_ERR_ARG, "nemo_solve_last_timing: null argument");
+  if (!ctx->ev_solve_valid) return fail(ctx, NEMO_ERR_STATE, "nemo_solve_last_timing: the last solve did not use tables");
+  HIP_TRY(ctx, hipEventSynchronize(ctx->ev_solve[2]));
+  HIP_TRY(ctx, hipEventElapsedTime(table_ms, ctx->ev_solve[0], ctx->ev_solve[1]));
+  HIP_TRY(ctx, hipEventElapsedTime(loop_ms, ctx->ev_solve[1], ctx->ev_solve[2]));
+  return NEMO_OK;
+}
+
 int64_t nemo_solve_table_capacity(const nemo_ctx *ctx) {
   if (!ctx || !ctx->d_tab || ctx->P.big || ctx->vmax_seen <= 0) return 0;
   const size_t stride = (size_t)ctx->vmax_seen * (size_t)ctx->cfg.win_h * ctx->cfg.win_w;
@@ -929,12 +942,14 @@ static int launch_solve(nemo_ctx *ctx, const char *who, int32_t N, const int32_t
     for (size_t k0 = 0; k0 < (size_t)N; k0 += tab_jobs) {
       const unsigned nk = (unsigned)std::min<size_t>(tab_jobs, (size_t)N - k0);
       const int32_t *ord = d_order ? d_order + k0 : nullptr;   // (no order: a single slice, slot y = job y)
+      if (k0 == 0) hipEventRecord(ctx->ev_solve[0], (hipStream_t)stream);
       if (D == 128)
         hipLaunchKernelGGL((bank_table_kernel<128>), dim3(wpj, nk), dim3(nt), lds, (hipStream_t)stream, d_feat, (int)hw,
                            d_img_idx, d_mesh_idx, (const MeshDesc *)ctx->d_meshes, ctx->d_tab, tab_stride, ord, (int)N);
       else
         hipLaunchKernelGGL((bank_table_kernel<256>), dim3(wpj, nk), dim3(nt), lds, (hipStream_t)stream, d_feat, (int)hw,
                            d_img_idx, d_mesh_idx, (const MeshDesc *)ctx->d_meshes, ctx->d_tab, tab_stride, ord, (int)N);
+      if (k0 == 0) hipEventRecord(ctx->ev_solve[1], (hipStream_t)stream);
 #define SOLVE_TAB(DD, PP)                                                                                                   \
   hipLaunchKernelGGL((solve_kernel<DD, PP, false, true>), dim3(nk), dim3(NT), ctx->lds, (hipStream_t)stream, ctx->P,        \
                      ctx->d_meshes, d_img_idx, d_mesh_idx, d_feat, d_clu, d_C0, d_theta0, d_trans0, ndof, ctx->d_adam,       \
@@ -943,10 +958,12 @@ static int launch_solve(nemo_ctx *ctx, const char *who, int32_t N, const int32_t
       if (D == 128) { if (ctx->P.persp) SOLVE_TAB(128, true); else SOLVE_TAB(128, false); }
       else          { if (ctx->P.persp) SOLVE_TAB(256, true); else SOLVE_TAB(256, false); }
 #undef SOLVE_TAB
+      if (k0 == 0) { hipEventRecord(ctx->ev_solve[2], (hipStream_t)stream); ctx->ev_solve_valid = 1; }
     }
     HIP_TRY(ctx, hipGetLastError());
     return NEMO_OK;
   }
+  ctx->ev_solve_valid = 0;
   DISPATCH_DP(solve_kernel, dim3(N), ctx->P, ctx->d_meshes, d_img_idx, d_mesh_idx, d_feat, d_clu, d_C0, d_theta0, d_trans0,
               ndof, ctx->d_adam, ctx->adam_steps, ctx->beta1, ctx->beta2, ctx->eps, d_pose, d_loss, d_trace, ctx->d_counter,
               stagger, d_order, (int)N, d_status, (const float *)nullptr, (size_t)0);

@@ -279,6 +279,9 @@ __global__ void solve_affinity_kernel(int N, int n_meshes, const int32_t *mesh_i
 // R, T to the workgroup through LDS; (C, theta) and the Adam moments live in LDS.
 // TAB: the per-job tables of feature-row x bank-row dot products exist (bank_table_kernel, launched just before);
 // the table of this workgroup's job is slot blockIdx.x: tab + blockIdx.x * tab_stride floats.
+#ifndef NEMO_RESORT_EVERY
+#define NEMO_RESORT_EVERY 8   // steps between two face sorts of the ordered rasteriser pass (a power of two)
+#endif
 template <int D, bool PERSP, bool BIG, bool TAB = false>
 __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc *meshes, const int32_t *img_idx,
                                                       const int32_t *mesh_idx, const float *feat, const float *clu,
@@ -315,7 +318,13 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
     if (NEMO_SOLVE_PRIO == 4 && w_ >= 12) __builtin_amdgcn_s_setprio(1);
   }
 #endif
+#ifdef NEMO_STAMPS
+  stamp_zero();
+#endif
   load_world_verts<BIG>(P, L, M);
+  if constexpr (TAB) {  // the ordered rasteriser pass (eval_pose) starts in face order
+    for (int i = threadIdx.x; i < M.F; i += NT) ((unsigned short *)L.fc)[4 * i + 3] = (unsigned short)i;
+  }
   loss_constant(P, L, c);
   const bool lead = threadIdx.x == 0;
   if (lead) {
@@ -353,7 +362,8 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
     // no closing barrier inside: thread 0 leaves eval_pose with the totals and goes straight on to Adam, the other
     // waves clear the z-buffer meanwhile (the score loop's scratch in that region is dead behind the band barrier)
     eval_pose<D, PERSP, true, true, false, false, BIG, false, TAB>(P, L, M, f, c, none, true, vreg,
-                                                                     TAB ? tab + (size_t)blockIdx.x * tab_stride : nullptr);
+                                                                     TAB ? tab + (size_t)blockIdx.x * tab_stride : nullptr,
+                                                                     TAB && (t & (NEMO_RESORT_EVERY - 1)) == 0);
     fetch_verts();
     for (int i = threadIdx.x; i < P.cap; i += NT) L.zb[i] = ~0ull;
 #ifdef NEMO_STAMPS
@@ -401,10 +411,14 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
 #ifdef NEMO_STAMPS
     if (threadIdx.x == 0) {
       const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();
-      atomicAdd(&g_stamps[7], now_ - st_lead);
+      stamp_lds()[7] += now_ - st_lead;
     }
 #endif
   }
+#ifdef NEMO_STAMPS
+  __syncthreads();
+  stamp_flush();
+#endif
   if (lead) {
     float *po = pose + (size_t)ndof * n;
     po[0] = L.ust[U_P]; po[1] = L.ust[U_P + 1]; po[2] = L.ust[U_P + 2]; po[3] = L.ust[U_P + 3];

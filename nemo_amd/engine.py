@@ -311,6 +311,14 @@ class PoseEngine:
         """Jobs per call the reserved dot-product tables hold (nemo_solve_table_capacity); 0 = the solve streams."""
         return int(self.lib.nemo_solve_table_capacity(self.ctx))
 
+    def solve_last_timing(self):
+        """(table_ms, loop_ms) of the last tables-form solve (nemo_solve_last_timing; synchronises); None if it streamed."""
+        import ctypes as C
+        a, b = C.c_float(), C.c_float()
+        if self.lib.nemo_solve_last_timing(self.ctx, C.byref(a), C.byref(b)) != 0:
+            return None
+        return float(a.value), float(b.value)
+
     def solve_uses_tables(self, n_jobs=1):
         return self.solve_table_capacity() >= max(1, int(n_jobs))
 
