@@ -261,7 +261,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
         // The dot products come from the job's table: one lane per entry, the entry's list word, clutter score and three
         // table values are fetched one chunk ahead (unconditionally, with a clamped index: exact wait counts).
         const gf32p gtab = as_global(tab);
-        const uint32_t hw32 = (uint32_t)(P.h * P.w);
+        const uint32_t hw32 = ((uint32_t)(P.h * P.w) + 31u) & ~31u;  // row length of the padded table (table_ld)
         uint32_t ent_c = 0u;
         float cl_c = 0.f, g_c[3] = {0.f, 0.f, 0.f};
         auto fetch = [&](int cb_, uint32_t &ent, float &cl, float (&g)[3]) {

@@ -1010,6 +1010,10 @@ __global__ __launch_bounds__(CkCfg<D>::NT) void clutter_kernel(const float *__re
   }
 }
 
+// Geometry of a padded table slot (see bank_table_kernel): row length and row count.
+__host__ __device__ inline uint32_t table_ld(uint32_t hw) { return (hw + 31u) & ~31u; }
+__host__ __device__ inline uint32_t table_rows(uint32_t vmax) { return (vmax + (uint32_t)CK_ROWS - 1u) / (uint32_t)CK_ROWS * (uint32_t)CK_ROWS; }
+
 // Per-job table of ALL feature-row x bank-row dot products: tab[n][v][p] = <bank_m(n)[v], feat_img(n)[p]>, f32
 // [N][tab_stride / hw rows][hw].  The three dot products the solve needs per covered pixel and Adam step do not depend
 // on the pose, so nemo_solve computes them once here -- a [V x D] . [D x hw] product per job on the fp32 matrix cores,
@@ -1017,8 +1021,11 @@ __global__ __launch_bounds__(CkCfg<D>::NT) void clutter_kernel(const float *__re
 // per covered pixel (eval_pose<TAB>).  Vertex-major rows: a lane owns a pixel column, so a stored accumulator row is 32
 // consecutive pixels (128 bytes), and the pixels of a face and of its neighbours share the table's cache lines.
 // Grid: (workgroups per job, jobs of the launch); slot y of the table belongs to the job workgroup y of the solve runs.
+// A slot is PADDED -- rows of ld = hw rounded up to 32 floats, a multiple of CK_ROWS rows (table_ld / table_rows) -- so
+// that every store of the kernel is unconditional: a predicated store costs a branch around it and, behind a branch, the
+// compiler can no longer count outstanding memory operations and waits for all of them.
 template <int D>
-__global__ __launch_bounds__(CkCfg<D>::NT) void bank_table_kernel(const float *__restrict__ feat, int hw,
+__global__ __launch_bounds__(CkCfg<D>::NT) void bank_table_kernel(const float *__restrict__ feat, int hw, int ld,
                                                                   const int32_t *img_idx, const int32_t *mesh_idx,
                                                                   const MeshDesc *meshes, float *__restrict__ tab,
                                                                   size_t tab_stride, const int32_t *order, int N) {
@@ -1062,18 +1069,29 @@ __global__ __launch_bounds__(CkCfg<D>::NT) void bank_table_kernel(const float *_
   const int stride = (int)gridDim.x * NWV;
   int base = (int)blockIdx.x * NWV;  // the workgroup's first tile of the round; every wave takes part in every round
   if (base >= ntiles) return;         // (barriers), waves past the end recompute the last tile and write nothing
-  f4 xc[D / 8];   // the tile's 32 feature rows; the next tile's are fetched at the end of a round (one exposed load
-  stage_load(0);  // latency per 17-chunk round; a second register set would spill the accumulators' store addresses)
-  load_x(min(base + wave, ntiles - 1), xc);
+  // Two register sets of feature rows at D = 128: the next tile's 32 rows are fetched under the matrix instructions of
+  // the round's last chunk.  (D = 256: 256 threads and 128 registers per set -- one set, the reload is exposed once per round.)
+  constexpr bool TWOX = D <= 128;
+  f4 xa[D / 8], xb[TWOX ? D / 8 : 1];
+  stage_load(0);
+  load_x(min(base + wave, ntiles - 1), xa);
   stage_store(0);
   __syncthreads();
   int buf = 0;
-  auto round = [&]() {
-    const int tile = base + wave;
+  const uint32_t uld = (uint32_t)ld;
+  typedef __attribute__((address_space(1))) char *gcharp;
+  auto round = [&](f4(&xc)[D / 8], f4(&xn)[TWOX ? D / 8 : 1]) {
+    // a wave past the end recomputes the last tile and stores the same values a second time
+    const int tile = min(base + wave, ntiles - 1);
     const int nbase = base + stride;
-    const int p = tile * 32 + i;
-    const bool pok = tile < ntiles && p < hw;
+    // C/D layout: column = lane & 31 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * half (bank row of the 32-row tile).
+    // A row's address = wave-uniform row base + one 32-bit per-lane byte offset (a slot is far below 4 GiB).
+    uint32_t boff = 4u * ((uint32_t)(tile * 32 + i) + (uint32_t)(4 * half) * uld);
+    asm volatile("" : "+v"(boff));   // opaque: stays ONE 32-bit register next to the scalar row bases
     for (int c = 0; c < nchunks; ++c) {
+      if constexpr (TWOX) {
+        if (c + 1 == nchunks && nbase < ntiles) load_x(min(nbase + wave, ntiles - 1), xn);
+      }
       if (nchunks > 1) stage_load(c + 1 == nchunks ? 0 : c + 1);
       const float *ap = cl + (size_t)buf * CK_ROWS * RS + i * RS + 4 * half;
       // rows i and 32 + i of the chunk against the tile's 32 pixels; the A operands are read one step ahead of the
@@ -1110,40 +1128,44 @@ __global__ __launch_bounds__(CkCfg<D>::NT) void bank_table_kernel(const float *_
         mm(o0, o1, xc[q + 1]);
         __builtin_amdgcn_sched_barrier(0);
       }
-      // C/D layout: column = lane & 31 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * half (bank row of the 32-row tile)
-      if (pok) {   // a job's table is far below 4 GiB: 32-bit offsets from one base
-        const uint32_t uhw = (uint32_t)hw;
-        const int vb = c * CK_ROWS + 4 * half;
-        uint32_t off = (uint32_t)vb * uhw + (uint32_t)p;
+      if (nchunks > 1) stage_store(buf ^ 1);   // before the stores: the wait for the staged rows must not wait for them
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        int crow = c * CK_ROWS;
+        asm volatile("" : "+s"(crow));   // opaque and scalar: keeps the row bases out of the loop's induction expressions
 #pragma unroll
-        for (int r8 = 0; r8 < 4; ++r8) {
-#pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) {
-            const int v0 = vb + r4 + 8 * r8;
-#ifndef NEMO_TAB_NT
-#define NEMO_TAB_NT 1
+        for (int j = 0; j < 32; ++j) {
+          const int r = j & 15, rr = (r & 3) + 8 * (r >> 2) + 32 * (j >> 4);
+          const float val = (j >> 4) ? acc1[r] : acc0[r];
+#ifndef NEMO_TAB_ABL
+#define NEMO_TAB_ABL 0   // diagnostic builds: 1 = no table stores, 2 = plain (cacheable) stores
 #endif
-            if (NEMO_TAB_NT) {
-              if (v0 < K) __builtin_nontemporal_store(acc0[4 * r8 + r4], gout + (off + (uint32_t)r4 * uhw));
-              if (v0 + 32 < K) __builtin_nontemporal_store(acc1[4 * r8 + r4], gout + (off + (uint32_t)(r4 + 32) * uhw));
-            } else {
-              if (v0 < K) gout[off + (uint32_t)r4 * uhw] = acc0[4 * r8 + r4];
-              if (v0 + 32 < K) gout[off + (uint32_t)(r4 + 32) * uhw] = acc1[4 * r8 + r4];
-            }
-          }
-          off += 8u * uhw;
+          const gcharp rowp = (gcharp)(gout + (size_t)(crow + rr) * uld);   // wave-uniform
+          __attribute__((address_space(1))) float *dst = (__attribute__((address_space(1))) float *)(rowp + boff);
+          if (NEMO_TAB_ABL == 0) __builtin_nontemporal_store(val, dst);
+          else if (NEMO_TAB_ABL == 2) *dst = val;
+          else if (val == 12345.678f) *dst = val;
         }
       }
       if (nchunks > 1) {
-        stage_store(buf ^ 1);
         __syncthreads();
         buf ^= 1;
       }
     }
-    if (nbase < ntiles) load_x(min(nbase + wave, ntiles - 1), xc);
+    if constexpr (!TWOX) {
+      if (nbase < ntiles) load_x(min(nbase + wave, ntiles - 1), xc);
+    }
     base = nbase;
   };
-  while (base < ntiles) round();
+  while (base < ntiles) {
+    if constexpr (TWOX) {
+      round(xa, xb);
+      if (base >= ntiles) break;
+      round(xb, xa);
+    } else {
+      round(xa, xb);
+    }
+  }
 }
 
 // Clutter score for a small bank (K <= 8; the reference's mean clutter vector is K = 1, code/MeshPoseSolveAll.py:207):

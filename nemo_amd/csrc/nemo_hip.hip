@@ -90,6 +90,7 @@ struct nemo_ctx {
   float *d_tab;
   size_t tab_cap;            // floats
   double env_solve_table_gb;
+  int env_table_wpj;         // NEMO_TABLE_WPJ: workgroups per job of bank_table_kernel
   hipEvent_t ev_solve[3];    // recorded around the table kernel and the solve kernel of the last table-form call (first slice)
   int ev_solve_valid;
   int env_grid_records;  // NEMO_GRID_RECORDS: -1 (default) the record store when the dense renders do not fit or G >= 4096; 0 never; 1 whenever it fits
@@ -118,6 +119,12 @@ static int hip_fail(nemo_ctx *ctx, hipError_t e, const char *what) {
   } while (0)
 
 // Sizes the LDS carve for the current largest mesh; called on registration.
+// floats per job in the solve's dot-product tables (padded slot, matrix_kernels.hpp); 0 before any mesh is registered
+static size_t table_stride(const nemo_ctx *ctx) {
+  if (ctx->vmax_seen <= 0) return 0;
+  return (size_t)table_rows((uint32_t)ctx->vmax_seen) * table_ld((uint32_t)(ctx->cfg.win_h * ctx->cfg.win_w));
+}
+
 static int plan_lds(nemo_ctx *ctx) {
   const nemo_config &c = ctx->cfg;
   const int vmax = ctx->vmax_seen > 0 ? ((ctx->vmax_seen + 63) & ~63) : 64;
@@ -352,6 +359,8 @@ int nemo_ctx_create(const nemo_config *cfg, nemo_ctx **out) {
   ctx->env_grid_no_mfma = env_int("NEMO_GRID_NO_MFMA", 0);
   ctx->env_solve_stagger = env_int("NEMO_SOLVE_STAGGER", 0);
   {
+    const char *w_ = getenv("NEMO_TABLE_WPJ");
+    ctx->env_table_wpj = w_ ? std::max(1, std::min(64, atoi(w_))) : 2;
     const char *e_ = getenv("NEMO_SOLVE_TABLE_GB");
     ctx->env_solve_table_gb = e_ ? atof(e_) : 64.0;
   }
@@ -406,8 +415,7 @@ int nemo_workspace_reserve(nemo_ctx *ctx, int32_t max_jobs, int32_t max_grid_pos
   // the solve's dot-product tables: as many jobs as fit NEMO_SOLVE_TABLE_GB, at most max_jobs (a call with more jobs goes
   // through in slices of that many; under 256 jobs' worth -- one per CU -- the solve streams the feature rows instead)
   {
-    const size_t hw = (size_t)ctx->cfg.win_h * ctx->cfg.win_w;
-    const size_t stride = (size_t)(ctx->vmax_seen > 0 ? ctx->vmax_seen : 0) * hw;
+    const size_t stride = table_stride(ctx);
     if (!ctx->P.big && stride > 0 && N > 0) {
       size_t jobs = (size_t)(ctx->env_solve_table_gb * 1073741824.0 / ((double)stride * 4.0));
       if (jobs > N) jobs = N;
@@ -883,8 +891,7 @@ int nemo_solve_last_timing(nemo_ctx *ctx, float *table_ms, float *loop_ms) {
 
 int64_t nemo_solve_table_capacity(const nemo_ctx *ctx) {
   if (!ctx || !ctx->d_tab || ctx->P.big || ctx->vmax_seen <= 0) return 0;
-  const size_t stride = (size_t)ctx->vmax_seen * (size_t)ctx->cfg.win_h * ctx->cfg.win_w;
-  return (int64_t)(ctx->tab_cap / stride);
+  return (int64_t)(ctx->tab_cap / table_stride(ctx));
 }
 
 int nemo_grid_store_kind(const nemo_ctx *ctx) {
@@ -933,22 +940,26 @@ static int launch_solve(nemo_ctx *ctx, const char *who, int32_t N, const int32_t
   // here instead of once per Adam step.  Same poses up to the summation order of a dot product; never for
   // large (BIG) meshes.  A call with more jobs than the tables hold goes through in slices of the launch order (which
   // then exists: such a call has more than 64 jobs): tables for a slice, then its solve, on the one stream.
-  const size_t hw = (size_t)ctx->cfg.win_h * ctx->cfg.win_w, tab_stride = (size_t)ctx->vmax_seen * hw;
+  const size_t hw = (size_t)ctx->cfg.win_h * ctx->cfg.win_w, tab_stride = table_stride(ctx);
   const size_t tab_jobs = (!ctx->P.big && ctx->d_tab && tab_stride > 0) ? ctx->tab_cap / tab_stride : 0;
   if (tab_jobs >= (size_t)N || (tab_jobs >= 256 && d_order)) {
     const int D = ctx->cfg.feat_dim, nt = D == 128 ? CkCfg<128>::NT : CkCfg<256>::NT;
     const size_t lds = (size_t)2 * CK_ROWS * (D + 4) * 4;
-    const unsigned wpj = (unsigned)std::min<size_t>(8, ((hw + 31) / 32 + (nt / 64) - 1) / (nt / 64));
+    // workgroups per job: a workgroup's prologue (first bank chunk, first feature rows) is exposed, so few, long
+    // workgroups -- NEMO_TABLE_WPJ (default 2) -- unless the call has too few jobs to fill the chip with them
+    unsigned wpj = (unsigned)ctx->env_table_wpj;
+    while ((size_t)wpj * (size_t)std::min<size_t>(tab_jobs, (size_t)N) < 512 && wpj < 8) wpj *= 2;
+    wpj = (unsigned)std::min<size_t>(wpj, ((hw + 31) / 32 + (nt / 64) - 1) / (nt / 64));
     for (size_t k0 = 0; k0 < (size_t)N; k0 += tab_jobs) {
       const unsigned nk = (unsigned)std::min<size_t>(tab_jobs, (size_t)N - k0);
       const int32_t *ord = d_order ? d_order + k0 : nullptr;   // (no order: a single slice, slot y = job y)
       if (k0 == 0) hipEventRecord(ctx->ev_solve[0], (hipStream_t)stream);
       if (D == 128)
         hipLaunchKernelGGL((bank_table_kernel<128>), dim3(wpj, nk), dim3(nt), lds, (hipStream_t)stream, d_feat, (int)hw,
-                           d_img_idx, d_mesh_idx, (const MeshDesc *)ctx->d_meshes, ctx->d_tab, tab_stride, ord, (int)N);
+                           (int)table_ld((uint32_t)hw), d_img_idx, d_mesh_idx, (const MeshDesc *)ctx->d_meshes, ctx->d_tab, tab_stride, ord, (int)N);
       else
         hipLaunchKernelGGL((bank_table_kernel<256>), dim3(wpj, nk), dim3(nt), lds, (hipStream_t)stream, d_feat, (int)hw,
-                           d_img_idx, d_mesh_idx, (const MeshDesc *)ctx->d_meshes, ctx->d_tab, tab_stride, ord, (int)N);
+                           (int)table_ld((uint32_t)hw), d_img_idx, d_mesh_idx, (const MeshDesc *)ctx->d_meshes, ctx->d_tab, tab_stride, ord, (int)N);
       if (k0 == 0) hipEventRecord(ctx->ev_solve[1], (hipStream_t)stream);
 #define SOLVE_TAB(DD, PP)                                                                                                   \
   hipLaunchKernelGGL((solve_kernel<DD, PP, false, true>), dim3(nk), dim3(NT), ctx->lds, (hipStream_t)stream, ctx->P,        \

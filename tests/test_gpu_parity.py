@@ -1457,7 +1457,7 @@ def test_solve_tables_against_streaming(oracle, monkeypatch, D, persp):
     th0 = (th + rng.normal(0, 0.04, n)).astype(np.float32)
     feats, clus = _dev(sc.feats), _dev(sc.clus)
     out = {}
-    stride_gb = sc.verts.shape[0] * sc.cfg.h * sc.cfg.w * 4 / 2 ** 30      # one job's table
+    stride_gb = (-(-sc.verts.shape[0] // 64) * 64) * (-(-(sc.cfg.h * sc.cfg.w) // 32) * 32) * 4 / 2 ** 30   # one job's (padded) table slot
     for mode, gb in (('tables', None), ('streaming', '0'), ('sliced', '%.6f' % (260 * stride_gb))):
         if gb is None:
             monkeypatch.delenv('NEMO_SOLVE_TABLE_GB', raising=False)

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nemo_amd.engine import PoseEngine
 eng = PoseEngine(100, (80, 100), 128)
 feats = torch.randn(1024, 80, 100, 128, device='cuda')
-for K in (1, 4, 8, 16, 32, 64, 512, 2560):
+for K in (1, 4, 8, 16, 32, 64, 512, 1088, 2560):
     cb = torch.nn.functional.normalize(torch.randn(K, 128, device='cuda'), dim=1).contiguous()
     eng.clutter_score(feats, cb); torch.cuda.synchronize()
     t0 = time.perf_counter()
