@@ -247,21 +247,30 @@ def launch_ranks(n_gpus, argv):
     return subprocess.call(cmd, env=env)
 
 
-PMC_FILE = 'profiles/r03_pmc_traffic.json'
+PMC_FILE = 'profiles/r03_pmc_traffic.json'            # streaming form of the solve
+PMC_TABLES_FILE = 'profiles/r03_pmc_solve_tables.json'  # tables form: bank_table_kernel + solve_kernel<TAB>
+TABLE_BYTES_PER_COVERED_PIXEL_STEP = 16  # tables form: three 4-byte dot products + the 4-byte clutter score
+
+
+def _pmc(fn, *keys):
+    """A figure from a committed PMC record (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE
+    doubled as the gfx950 note in MI355X_MICROARCH.md prescribes).  bench.py cannot collect counters itself; None if
+    the file or the key is missing."""
+    try:
+        with open(os.path.join(ROOT, fn)) as f:
+            v = json.load(f)
+        for k in keys:
+            v = v[k]
+        return float(v)
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
 
 
 def pmc_traffic(cov_steps):
-    """HBM bytes per launch of the solve kernel, SCALED from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE
-    and WRITE_SIZE in separate runs of this workload, FETCH_SIZE doubled as the gfx950 note in MI355X_MICROARCH.md
-    prescribes): bytes per covered pixel-step of that pass x this launch's covered pixel-steps.  bench.py cannot
-    collect counters itself; None if the file is missing."""
-    fn = os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_FILE)
-    try:
-        with open(fn) as f:
-            per = json.load(f)['solve_kernel']['hbm_bytes_per_covered_pixel_step']
-        return float(per) * float(cov_steps)
-    except (OSError, KeyError, ValueError):
-        return None
+    """HBM bytes per launch of the streaming solve kernel, SCALED from the committed PMC passes: bytes per covered
+    pixel-step of that pass x this launch's covered pixel-steps."""
+    per = _pmc(PMC_FILE, 'solve_kernel', 'hbm_bytes_per_covered_pixel_step')
+    return None if per is None else per * float(cov_steps)
 
 
 def main():
@@ -331,13 +340,16 @@ def main():
     nd.fence(dev)
     dt = nd.max_over_ranks(time.perf_counter() - t0, dev)
 
-    # ---- dominant kernel (fused solve) timed alone with HIP events on the launch stream
+    # ---- the solve timed alone.  Tables form (the default when the reserved workspace holds the tables): two kernels,
+    # bank_table_kernel (all feature-row x bank-row dot products of a job, once, on the matrix cores) and
+    # solve_kernel<TAB> (the 300 steps); the library records HIP events around both on the launch stream
+    # (nemo_solve_last_timing).  Streaming form: the one solve_kernel, torch events on the same (current) stream.
     clu = eng.clutter_score(wl.feats, wl.clutter)
     C0, th0, _, _ = eng.grid_search(wl.feats, clu, solver.grid_C, solver.grid_theta, mesh_idx=wl.mesh_idx,
                                     grid_idx=wl.mesh_idx)
     torch.cuda.synchronize(dev)
     eng.counter_reset()
-    evs = []
+    evs, tabs = [], []
     reps = max(1, args.steps)
     for _ in range(reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -345,11 +357,61 @@ def main():
         eng.solve(wl.feats, clu, C0, th0, mesh_idx=wl.mesh_idx)
         b.record()
         evs.append((a, b))
+        tabs.append(eng.solve_last_timing())   # (table_ms, loop_ms) or None; synchronises
     torch.cuda.synchronize(dev)
     solve_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     cov_steps = eng.counter_read() / reps  # covered pixel-steps of one solve launch
-    alg_bytes = cov_steps * eng.bytes_per_covered_pixel()
-    achieved = alg_bytes / (solve_ms * 1e-3) / 1e9
+    stream_bytes = cov_steps * eng.bytes_per_covered_pixel()   # n_cov (4 D + 4) per job-step
+    working_set = float(min(args.images, 256)) * stream_bytes / max(1, args.images * solver.cfg.total_epochs)
+    extra = {}
+    if all(t is not None for t in tabs):
+        table_ms = float(np.mean([t[0] for t in tabs]))
+        loop_ms = float(np.mean([t[1] for t in tabs]))
+        hw = eng.h * eng.w
+        verts = np.asarray([int(v.shape[0]) for v, _, _ in eng._keep], dtype=np.float64)
+        flops = float((2.0 * verts[wl.mesh_idx.cpu().numpy()] * hw * eng.D).sum())   # 2 V hw D per job
+        loop_bytes = cov_steps * TABLE_BYTES_PER_COVERED_PIXEL_STEP
+        per_loop = _pmc(PMC_TABLES_FILE, 'solve_kernel', 'hbm_bytes_per_covered_pixel_step')
+        per_tab = _pmc(PMC_TABLES_FILE, 'bank_table_kernel', 'hbm_bytes_per_job')
+        tf = flops / (table_ms * 1e-3) / 1e12
+        roof = {'bound': 'hbm', 'achieved': loop_bytes / (loop_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': loop_bytes / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                'traffic': None if per_loop is None else per_loop * cov_steps,
+                'kernel': 'solve_kernel<TAB>', 'kernel_ms': loop_ms, 'algorithmic_bytes_per_launch': loop_bytes,
+                'bytes_per_covered_pixel_step': TABLE_BYTES_PER_COVERED_PIXEL_STEP,
+                'covered_pixel_steps_per_launch': cov_steps,
+                'traffic_source': f'scaled from the committed PMC pass {PMC_TABLES_FILE} (not read during this run)',
+                'note': 'the dominant kernel by time.  In the tables form it is NOT bound by HBM (nor by the matrix cores): its '
+                        '300 steps project, rasterise, list and score a job per step on the vector ALUs and the LDS (SQ '
+                        'counters: vector ALUs issuing about two thirds of the time, profiles/r03_sq_solve_tables.txt); per '
+                        'covered pixel and step it reads 16 bytes where the streaming form read 516.  `traffic` above '
+                        '`algorithmic bytes`: a 4-byte table read fetches a cache line'}
+        extra['roofline_table'] = {
+            'bound': 'mfma', 'achieved': tf, 'peak': MFMA_FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / MFMA_FP32_PEAK_TFLOPS,
+            'traffic': None if per_tab is None else per_tab * args.images, 'kernel': 'bank_table_kernel', 'kernel_ms': table_ms,
+            'flops_per_launch': flops, 'dtype': 'f32',
+            'note': 'second kernel of the solve: [V x D] . [D x h w] per job on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains), '
+                    '2 V h w D flops per job; its traffic is the table it writes (V h w 4 bytes per job) plus the maps it reads once'}
+        extra['roofline_streaming_equivalent'] = {
+            'bound': 'hbm', 'achieved': stream_bytes / ((table_ms + loop_ms) * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': stream_bytes / ((table_ms + loop_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 'kernel': 'bank_table_kernel + solve_kernel<TAB>',
+            'kernel_ms': table_ms + loop_ms, 'algorithmic_bytes_per_launch': stream_bytes,
+            'note': 'continuity with rounds 1-2 (frac 0.63-0.65): SURVEY 8(d)\'s per-unit figure, n_cov (4 D + 4) bytes per job-step '
+                    '-- what the streaming formulation of the solve must move -- divided by the time of the two kernels that '
+                    'replace it.  Above 1: those bytes are no longer moved; the contraction they fed is done once per solve'}
+    else:
+        achieved = stream_bytes / (solve_ms * 1e-3) / 1e9
+        roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(cov_steps), 'kernel': 'solve_kernel',
+                'traffic_source': f'scaled from the committed PMC pass {PMC_FILE} (not read during this run)',
+                'kernel_ms': solve_ms, 'algorithmic_bytes_per_launch': stream_bytes,
+                'covered_pixel_steps_per_launch': cov_steps,
+                # what the resident jobs (one workgroup per CU) re-read every Adam step, against the 256 MiB
+                # Infinity Cache: FETCH_SIZE counts L2 misses whether the Infinity Cache or HBM serves them,
+                # so `frac` (algorithmic bytes / time) is an upper bound on DRAM utilisation
+                'working_set_bytes': working_set, 'infinity_cache_bytes': 256 * 2 ** 20}
+    roof['solve_form'] = 'tables' if extra else 'streaming'
+    roof['solve_ms'] = solve_ms
 
     if rank == 0:
         ok = torch.isfinite(res.campos).all(dim=1).float().mean().item()
@@ -374,18 +436,10 @@ def main():
                        'raster': eng.S, 'grid_poses': int(solver.grid_theta.shape[1]),
                        'adam_steps': solver.cfg.total_epochs, 'parallelism': f'images sharded over {world} GPU(s)'
                        + (f' [REHEARSAL: {world} ranks share one GPU, gloo]' if args.share_gpu else '')},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(cov_steps), 'kernel': 'solve_kernel',
-                         'traffic_source': f'scaled from the committed PMC pass {PMC_FILE} (not read during this run)',
-                         'kernel_ms': solve_ms, 'algorithmic_bytes_per_launch': alg_bytes,
-                         'covered_pixel_steps_per_launch': cov_steps,
-                         # what the resident jobs (one workgroup per CU) re-read every Adam step, against the 256 MiB
-                         # Infinity Cache: FETCH_SIZE counts L2 misses whether the Infinity Cache or HBM serves them,
-                         # so `frac` (algorithmic bytes / time) is an upper bound on DRAM utilisation
-                         'working_set_bytes': float(min(args.images, 256)) * alg_bytes / max(1, args.images * solver.cfg.total_epochs),
-                         'infinity_cache_bytes': 256 * 2 ** 20},
+            'roofline': roof,
             'quality': {'finite_fraction': ok, 'median_err_deg_vs_synthetic_gt': float(np.degrees(np.median(errs)))},
         }
+        out.update(extra)
         if world == 1:
             out['roofline_mfma'] = roofline_mfma(eng, wl.feats)
         if world == 1 and args.from_files_images > 0:

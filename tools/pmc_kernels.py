@@ -22,15 +22,16 @@ def sums(d, counter):
     return acc, calls
 
 
-f, fc = sums(sys.argv[1], 'FETCH_SIZE')
-w, wc = sums(sys.argv[2], 'WRITE_SIZE')
-out = {'command': sys.argv[4] if len(sys.argv) > 4 else '', 'note': 'bytes; FETCH_SIZE x 1024 x 2 (gfx950 correction), WRITE_SIZE x 1024', 'kernels': {}}
-for k in sorted(f, key=lambda k: -(f[k] * 2 + w.get(k, 0))):
-    fb, wb = f[k] * 2048, w.get(k, 0.0) * 1024
-    if fb + wb < 1e8:
-        continue
-    out['kernels'][k] = {'calls': fc[k], 'fetch_bytes_total': fb, 'write_bytes_total': wb,
-                         'hbm_bytes_per_call': (fb + wb) / max(fc[k], 1)}
-json.dump(out, open(sys.argv[3], 'w'), indent=1)
-for k, v in out['kernels'].items():
-    print(f"{k:40s} calls {v['calls']:4d}  per call {v['hbm_bytes_per_call'] / 1e9:9.3f} GB")
+if __name__ == '__main__':
+    f, fc = sums(sys.argv[1], 'FETCH_SIZE')
+    w, wc = sums(sys.argv[2], 'WRITE_SIZE')
+    out = {'command': sys.argv[4] if len(sys.argv) > 4 else '', 'note': 'bytes; FETCH_SIZE x 1024 x 2 (gfx950 correction), WRITE_SIZE x 1024', 'kernels': {}}
+    for k in sorted(f, key=lambda k: -(f[k] * 2 + w.get(k, 0))):
+        fb, wb = f[k] * 2048, w.get(k, 0.0) * 1024
+        if fb + wb < 1e8:
+            continue
+        out['kernels'][k] = {'calls': fc[k], 'fetch_bytes_total': fb, 'write_bytes_total': wb,
+                             'hbm_bytes_per_call': (fb + wb) / max(fc[k], 1)}
+    json.dump(out, open(sys.argv[3], 'w'), indent=1)
+    for k, v in out['kernels'].items():
+        print(f"{k:40s} calls {v['calls']:4d}  per call {v['hbm_bytes_per_call'] / 1e9:9.3f} GB")

@@ -8,7 +8,7 @@ for d in sys.argv[1:]:
             k = r['Kernel_Name'][:60]
             acc[k][r['Counter_Name']] += float(r['Counter_Value']); nd[k].add(r['Dispatch_Id'])
         for k, v in acc.items():
-            if 'solve_kernel' in k or 'grid_kernel' in k or 'clutter' in k or 'grid_mfma' in k:
+            if 'solve_kernel' in k or 'bank_table' in k or 'grid_kernel' in k or 'clutter' in k or 'grid_mfma' in k:
                 print(fn.split('/')[-3], k, 'dispatches', len(nd[k]))
                 for c, x in v.items():
                     print(f'    {c:28s} {x:.4g}')

@@ -18,6 +18,11 @@ for step in "$@"; do
     pmc)      for c in FETCH_SIZE WRITE_SIZE; do
                 timeout -s KILL 150 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 tools/prof_solve.py --images 1024 --steps 300 --reps 1 --grid > $O/pmc_$c.log 2>&1 || exit 1
               done ;;
+    pmc_tables) for c in FETCH_SIZE WRITE_SIZE; do
+                timeout -s KILL 150 rocprofv3 --pmc $c --output-format csv -d $O/pmct_$c -- python3 tools/prof_solve.py --images 1024 --steps 300 --reps 1 > $O/pmct_$c.log 2>&1 || exit 1
+              done
+              python3 tools/pmc_tables_summary.py $O/pmct_FETCH_SIZE $O/pmct_WRITE_SIZE $O/pmct_FETCH_SIZE.log $O/pmc_solve_tables.json 1024 || exit 1 ;;
+    sq_tables) bash tools/pmc_sq.sh "" r03tab > $O/sq_solve_tables.txt 2>&1 || exit 1 ;;
     pmc_dense12) for c in FETCH_SIZE WRITE_SIZE; do
                 timeout -s KILL 200 rocprofv3 --pmc $c --output-format csv -d $O/pmcd12_$c -- python3 tools/bench_configs.py dense12 > $O/pmcd12_$c.log 2>&1 || exit 1
               done
