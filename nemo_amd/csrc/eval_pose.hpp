@@ -80,10 +80,19 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
     L.red[wave * RED_N + 2] = tmin; L.red[wave * RED_N + 3] = tmax;
   }
   __syncthreads();
-#pragma unroll
-  for (int k = 0; k < NW; ++k) {
-    umin = fminf(umin, L.red[k * RED_N + 0]); umax = fmaxf(umax, L.red[k * RED_N + 1]);
-    tmin = fminf(tmin, L.red[k * RED_N + 2]); tmax = fmaxf(tmax, L.red[k * RED_N + 3]);
+  {
+    // the NW waves' boxes -> the workgroup's: lane (row j = value, k = wave) reads one number, maxima negated so that the
+    // four rows of 16 reduce with the same four DPP minimum steps (exact: negation and min / max commute)
+    static_assert(NW <= 16, "one DPP row per value");
+    const int j = lane >> 4, k = min(lane & 15, NW - 1);
+    float r = L.red[k * RED_N + j];
+    r = (j & 1) ? -r : r;
+    r = fminf(r, dpp_mov<0xB1>(r)); r = fminf(r, dpp_mov<0x4E>(r));
+    r = fminf(r, dpp_mov<0x141>(r)); r = fminf(r, dpp_mov<0x140>(r));
+    umin = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 0));
+    umax = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 16));
+    tmin = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 32));
+    tmax = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 48));
   }
   // Flipped pixel indices a = S-1-col, b = S-1-row: pixel centre = ndc_of(a), ndc_of(b).
   // Conservative index range of the object's bounding box, clipped to the window.
@@ -755,14 +764,12 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       int *ired = (int *)L.red;
       if (lane == 63) ired[wave * RED_N + 8] = incl;
       __syncthreads();
-      int slot = incl - cnt, ntot = 0;
-#pragma unroll
-      for (int k = 0; k < NW; ++k) {
-        const int t = ired[k * RED_N + 8];
-        slot += (k < wave) ? t : 0;
-        ntot += t;
-      }
-      ntot = __builtin_amdgcn_readfirstlane(ntot);
+      // the waves' totals: lane k < NW reads wave k's, a row scan gives every wave its base and the grand total
+      int wt = (lane < NW) ? ired[lane * RED_N + 8] : 0;
+      wt += dpp_shr0<0x111>(wt); wt += dpp_shr0<0x112>(wt); wt += dpp_shr0<0x114>(wt); wt += dpp_shr0<0x118>(wt);
+      const int ntot = __builtin_amdgcn_readlane(wt, NW - 1);
+      const int slot0 = wave > 0 ? __builtin_amdgcn_readlane(wt, max(wave - 1, 0)) : 0;
+      int slot = incl - cnt + slot0;
       if (cnt > 0)
         for (int f = fbeg; f < fend; ++f) {
           const u4v fi = finfo_at<BIG>(L, f);
