@@ -201,9 +201,11 @@ int nemo_solve(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t
  *    row with the three bank rows of its face.  None of that depends on the pose, so the call first computes ALL
  *    feature-row x bank-row products of every job on the matrix cores (f32 [job][V][win_h*win_w], 35 MB per job at
  *    V = 1088 and an 80 x 100 window) and its Adam steps read three floats per covered pixel.  The tables live in the
- *    workspace sized by nemo_workspace_reserve(ctx, max_jobs, ...): max_jobs x (largest registered mesh) x window x 4
- *    bytes, allocated only when that is within NEMO_SOLVE_TABLE_GB (environment, read at nemo_ctx_create; default 64,
- *    0 = never).  A call uses them when its N jobs fit the reservation; never for meshes whose tables do not fit the LDS.
+ *    workspace sized by nemo_workspace_reserve(ctx, max_jobs, ...): max_jobs x (vertices of the largest registered mesh,
+ *    rounded up to 64) x (window pixels, rounded up to 32) x 4 bytes, allocated only when that is within
+ *    NEMO_SOLVE_TABLE_GB (environment, read at nemo_ctx_create; default 64, 0 = never); with room for at least 256 jobs
+ *    a larger call goes through in slices.  Never for meshes whose tables do not fit the LDS.  NEMO_TABLE_WPJ
+ *    (default 2): workgroups per job of the table kernel.
  *  - STREAMING (otherwise): every Adam step reads the covered pixels' feature rows (4*D + 4 bytes per covered pixel and
  *    step) and contracts them with the bank rows in the kernel.
  * nemo_solve_table_capacity: the number of jobs the reserved tables hold for the meshes registered so far (0: streaming). */
