@@ -70,9 +70,9 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
     }
   }
   const bool ordered = TAB && !BIG && F <= 2 * NT;
-  // 64 bin counters of the face sort, in the unused slots 4..7 of the 16 rows of L.red (zeroed ahead of the barrier below)
-  int *const sort_bins = (int *)L.red;
-  auto bin_at = [&](int b) -> int & { return sort_bins[(b >> 2) * RED_N + 4 + (b & 3)]; };
+  // 64 bin counters of the face sort, in the per-face record area (TAB keeps no records; zeroed ahead of the barrier below)
+  int *const sort_bins = (int *)L.finfo;
+  auto bin_at = [&](int b) -> int & { return sort_bins[b]; };
   if (TAB && resort && tid < 64) bin_at(tid) = 0;
   umin = wave_min(umin); umax = wave_max(umax); tmin = wave_min(tmin); tmax = wave_max(tmax);
   if (lane == 0) {
@@ -135,6 +135,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
   unsigned long long st_score0 = 0;
 #endif
   float tot = 0.0f;  // wave 0, lane i < 13: running total i of the evaluation (T_LOSS, T_GR.., T_GT..)
+  int tab_bw = 1, tab_a_lo = 0, tab_bb = 0, tab_wcnt = 0;  // TAB: geometry of the band whose z-buffer `consume` compacts
   auto consume = [&](const int ntot, const int ebase, const bool last) {
     if (!SCORE) {
       // pre-render: keep the list itself; standalone rasterizer: emit pix_to_face / bary / zbuf
@@ -267,6 +268,40 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
           }
       };
       if constexpr (TAB) {
+        // TAB: there is no workgroup-wide list.  `ntot` is the number of z-buffer entries of the band; a wave owns
+        // contiguous runs of entries (below) and compacts the covered ones IN PLACE (64 keys are read,
+        // then their list words -- face << 16 | window pixel, in entry order -- overwrite the low end of the wave's
+        // own segment: a write never reaches an entry that is still to be read, and the LDS operations of a wave
+        // complete in order) and scores them straight away: no count pass, no scan, no fill, no barrier between the
+        // rasteriser's and the end of the score.  Entry order is row-major over the object's box, so every float sum
+        // is still a fixed function of the z-buffer contents.
+        // Balance: coverage is low in the top and bottom rows of the object's box and high in the middle, so a wave owns
+        // TWO segments, sub-bands w and w + NW of 2 NW; the list of both lives in the larger one ("home", compacted
+        // first), which has room for both: 2 |home| words >= |home| + |other| entries.
+        auto sub_b = [&](int k) { return (ntot * k) / (2 * NW); };
+        const int sA_b = sub_b(wave), sA_e = sub_b(wave + 1), sB_b = sub_b(wave + NW), sB_e = sub_b(wave + NW + 1);
+        const bool home_a = (sA_e - sA_b) >= (sB_e - sB_b);
+        uint32_t *const zw = (uint32_t *)L.zb;   // entry i: face id = low dword = zw[2 i]
+        uint32_t *const wl = zw + 2 * (home_a ? sA_b : sB_b);      // the wave's list
+        int wcnt = 0;
+        const float inv_bw = 1.0f / (float)tab_bw;
+        auto compact = [&](const int zs_b, const int zs_e) {
+          for (int i0 = zs_b; i0 < zs_e; i0 += 64) {
+            const int i = i0 + lane;
+            const uint32_t f = (i < zs_e) ? zw[2 * i] : 0xffffffffu;
+            const bool cov = f != 0xffffffffu;
+            const u64 bal = __ballot(cov);
+            const int pre = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            // row / column of entry i in the band (estimate by reciprocal, corrected: exact)
+            int row = (int)((float)i * inv_bw), col = i - row * tab_bw;
+            if (col < 0) { --row; col += tab_bw; }
+            if (col >= tab_bw) { ++row; col -= tab_bw; }
+            const int a = tab_a_lo + col, b = tab_bb + row;
+            if (cov) wl[wcnt + pre] = (f << 16) | (uint32_t)((S - 1 - b - P.r0) * P.w + (S - 1 - a - P.c0));
+            wcnt += __builtin_popcountll(bal);
+          }
+        };
+        if (home_a) { compact(sA_b, sA_e); compact(sB_b, sB_e); } else { compact(sB_b, sB_e); compact(sA_b, sA_e); }
         // The dot products come from the job's table: one lane per entry, the entry's list word, clutter score and three
         // table values are fetched one chunk ahead (unconditionally, with a clamped index: exact wait counts).
         const gf32p gtab = as_global(tab);
@@ -274,23 +309,24 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
         uint32_t ent_c = 0u;
         float cl_c = 0.f, g_c[3] = {0.f, 0.f, 0.f};
         auto fetch = [&](int cb_, uint32_t &ent, float &cl, float (&g)[3]) {
-          const int e_ = min(cb_ + lane, max(seg_e - 1, seg_b));
-          ent = L.list[min(e_, max(ntot - 1, 0))];
+          ent = wl[min(cb_ + lane, wcnt - 1)];
           const uint32_t px = ent & 0xffffu;
           cl = (P.clutter && clu) ? gclu[px] : 0.0f;
           const us4 fv_ = fc_at<BIG>(L, ent >> 16);
           g[0] = gtab[(uint32_t)fv_.x * hw32 + px]; g[1] = gtab[(uint32_t)fv_.y * hw32 + px]; g[2] = gtab[(uint32_t)fv_.z * hw32 + px];
         };
-        if (cb < seg_e) fetch(cb, ent_c, cl_c, g_c);
-        while (cb < seg_e) {
-          const int cn = min(CH, seg_e - cb);
+        int cbt = 0;
+        if (wcnt > 0) fetch(0, ent_c, cl_c, g_c);
+        while (cbt < wcnt) {
+          const int cn = min(CH, wcnt - cbt);
           uint32_t ent_n;
           float cl_n, g_n[3];
-          fetch(cb + CH, ent_n, cl_n, g_n);
+          fetch(cbt + CH, ent_n, cl_n, g_n);
           if (lane < cn) phase_b(ent_c, cl_c, g_c[0], g_c[1], g_c[2]);
           ent_c = ent_n; cl_c = cl_n; g_c[0] = g_n[0]; g_c[1] = g_n[1]; g_c[2] = g_n[2];
-          cb += CH;
+          cbt += CH;
         }
+        tab_wcnt = wcnt;
       }
       if constexpr (!TAB) {
 #if NEMO_PHASEA_MFMA
@@ -543,6 +579,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
         if (lane == 0) {
 #pragma unroll
           for (int i = 0; i < NP; ++i) L.red[wave * RED_N + i] = pv[i];
+          if (TAB) L.red[wave * RED_N + 13] = (float)tab_wcnt;   // the wave's covered pixels (exact: far below 2^24)
         }
       }
     }
@@ -560,7 +597,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
 #endif
     if (SCORE) {
       // the waves' partials -> running totals, in wave order: lane i of wave 0 keeps total i in a register
-      constexpr int NPB = GRAD ? 13 : 1;
+      constexpr int NPB = TAB ? 14 : (GRAD ? 13 : 1);   // TAB: lane 13 totals the waves' covered-pixel counts
       if (wave == 0 && lane < NPB) {
 #pragma unroll
         for (int k = 0; k < NW; ++k) tot += L.red[k * RED_N + lane];
@@ -674,10 +711,12 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
                 if (!(pz < 0.0f) && b0 > 0.0f && b1 > 0.0f && b2 > 0.0f) {
                   const u64 key = ((u64)__float_as_uint(pz + 0.0f) << 32) | (u64)(uint32_t)f;  // -0 -> +0: key order = float order
                   atomicMin(&zrow[a], key);
-                  fmask |= 1ull << (bit & 63);
-                  if (__builtin_expect(!use_mask, 0)) {
-                    ha_lo = min(ha_lo, a); ha_hi = max(ha_hi, a);
-                    hb_lo = min(hb_lo, b); hb_hi = max(hb_hi, b);
+                  if constexpr (!TAB) {   // (TAB builds no list from per-face records)
+                    fmask |= 1ull << (bit & 63);
+                    if (__builtin_expect(!use_mask, 0)) {
+                      ha_lo = min(ha_lo, a); ha_hi = max(ha_hi, a);
+                      hb_lo = min(hb_lo, b); hb_hi = max(hb_hi, b);
+                    }
                   }
                 }
               }
@@ -698,7 +737,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
             }
           }
         }
-        finfo_put<BIG>(L, f, rec);
+        if constexpr (!TAB) finfo_put<BIG>(L, f, rec);
         if constexpr (TAB) {
           if (sort_now) {  // every face is visited exactly once: the ranks inside a bin are a permutation of it
             const int key = min(ncand_f, 63);
@@ -727,6 +766,12 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
         }
       }
       STAMP(2);
+      if constexpr (TAB) {
+        tab_bw = bw; tab_a_lo = a_lo; tab_bb = bb;
+        STAMP(3);
+        consume(npx, ebase, bb + rows_per_band > b_hi);
+        continue;
+      }
       // ---- 2c. face-major list of the covered pixels: ordered by winning face, then
       // row-major.  Thread t owns the contiguous face run [t*fpl, (t+1)*fpl), so a
       // block-wide exclusive scan of the per-thread counts gives every thread its slot
@@ -803,9 +848,10 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       float tv[13];
 #pragma unroll
       for (int i = 0; i < 13; ++i) tv[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), i));
+      const float ncov_tab = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), 13));
       if (tid == 0) {
         L.ust[U_TOT + T_LOSS] = tv[0];
-        L.ust[U_TOT + T_NCOV] = (float)ncov;
+        L.ust[U_TOT + T_NCOV] = TAB ? ncov_tab : (float)ncov;
         if (GRAD) {
           const float *R = L.ust + U_R;
 #pragma unroll
