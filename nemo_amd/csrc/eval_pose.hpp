@@ -49,6 +49,10 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
   if (!SCORE && tid < 16) L.ust[U_TOT + tid] = 0.0f;  // ordered before any use by the bounding-box barrier
   // ---- 1. project vertices (MeshRasterizer.transform; order fixed in DESIGN.md)
   float umin = 3.0e38f, umax = -3.0e38f, tmin = 3.0e38f, tmax = -3.0e38f;
+  // TAB keeps no workgroup-wide list: its area hosts the per-vertex backward table (when it is large enough)
+  f4 *const xv = (f4 *)L.list;
+  const bool use_xv = TAB && !BIG && P.cap >= 4 * P.vmax;
+  const float xv_inv_s = 1.0f / s;
   {
     const float *R = L.ust + U_R, *T = L.ust + U_T;
     const float m00 = R[0] * s, m10 = R[3] * s, m20 = R[6] * s, m30 = T[0] * s;
@@ -65,6 +69,14 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       const float zv = ((x * r02 + y * r12) + z * r22) + t2;
       const float u = xc / zv, t = yc / zv;
       sv_put<BIG>(L, v, f4{u, t, zv, 0.0f});
+      if constexpr (TAB) {
+        // what the backward needs per vertex (view-space position minus T, 1 / z): once per vertex here instead of once per
+        // covered pixel and vertex in phase B -- the same expressions, so the same bits
+        if (use_xv) {
+          const float iz = __builtin_amdgcn_rcpf(zv), zs = zv * xv_inv_s;
+          xv[v] = f4{u * zs - T[0], t * zs - T[1], zv - T[2], iz};
+        }
+      }
       umin = fminf(umin, u); umax = fmaxf(umax, u);
       tmin = fminf(tmin, t); tmax = fmaxf(tmax, t);
     }
@@ -251,15 +263,20 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
             const float inv_s = 1.0f / s, T0 = L.ust[U_T], T1 = L.ust[U_T + 1], T2 = L.ust[U_T + 2];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-              const float iz = __builtin_amdgcn_rcpf(v[3 * c + 2]);
+              float iz, X0, X1, X2;
+              // world vertex = (view - T) R^T: accumulate against (view - T) and rotate the 3x3 total once
+              // at the end (no world-space vertex table in LDS)
+              if (TAB && use_xv) {
+                const f4 xx = xv[vi[c]];
+                X0 = xx.x; X1 = xx.y; X2 = xx.z; iz = xx.w;
+              } else {
+                iz = __builtin_amdgcn_rcpf(v[3 * c + 2]);
+                const float zs = v[3 * c + 2] * inv_s;
+                X0 = v[3 * c] * zs - T0; X1 = v[3 * c + 1] * zs - T1; X2 = v[3 * c + 2] - T2;
+              }
               const float gxc = gv[3 * c] * iz, gyc = gv[3 * c + 1] * iz;
               const float gzv = gv[3 * c + 2] - (gv[3 * c] * v[3 * c] + gv[3 * c + 1] * v[3 * c + 1]) * iz;
               const float q0 = s * gxc, q1 = s * gyc, q2 = gzv;
-              // world vertex = (view - T) R^T: accumulate against (view - T) and rotate the 3x3 total once
-              // at the end (no world-space vertex table in LDS)
-              const float zs = v[3 * c + 2] * inv_s;
-              const float X0 = v[3 * c] * zs - T0, X1 = v[3 * c + 1] * zs - T1, X2 = v[3 * c + 2] - T2;
-              (void)vi;
               GR[0] = fmaf(X0, q0, GR[0]); GR[1] = fmaf(X0, q1, GR[1]); GR[2] = fmaf(X0, q2, GR[2]);
               GR[3] = fmaf(X1, q0, GR[3]); GR[4] = fmaf(X1, q1, GR[4]); GR[5] = fmaf(X1, q2, GR[5]);
               GR[6] = fmaf(X2, q0, GR[6]); GR[7] = fmaf(X2, q1, GR[7]); GR[8] = fmaf(X2, q2, GR[8]);
