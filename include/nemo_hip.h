@@ -208,12 +208,22 @@ int nemo_solve(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t
  *    (default 2): workgroups per job of the table kernel.
  *  - STREAMING (otherwise): every Adam step reads the covered pixels' feature rows (4*D + 4 bytes per covered pixel and
  *    step) and contracts them with the bank rows in the kernel.
+ *    By default the tables are filled ON DEMAND (NEMO_SOLVE_LAZY, environment, default 1): the solve kernel keeps a bitmap
+ *    of (32 vertices x 32 pixels) blocks per job in LDS and a wave computes the blocks its pixels need and that do not
+ *    exist yet, itself, on the matrix cores, before it scores them -- bit for bit the values the whole-table kernel
+ *    writes; about a fifth of a job's blocks are ever computed.  Used when the largest registered mesh has at most 2048
+ *    vertices; NEMO_SOLVE_LAZY=0: bank_table_kernel fills every job's whole table ahead of the solve kernel.
  * nemo_solve_table_capacity: the number of jobs the reserved tables hold for the meshes registered so far (0: streaming). */
 int64_t nemo_solve_table_capacity(const nemo_ctx *ctx);
 /* Measurement aid, no counterpart in the reference: device time of the two kernels of the last TABLES-form solve call of
  * this context (its first slice) -- bank_table_kernel and solve_kernel -- from events the call records on its stream.
  * SYNCHRONISES on the last of them.  NEMO_ERR_STATE if the last solve streamed. */
 int nemo_solve_last_timing(nemo_ctx *ctx, float *table_ms, float *loop_ms);
+/* Measurement aid, no counterpart in the reference.  mode: form of the last solve call of this context -- 0 streaming,
+ * 1 tables filled whole by bank_table_kernel, 2 tables filled on demand inside the solve kernel (the default; see
+ * NEMO_SOLVE_LAZY above); blocks: (32 vertices x 32 pixels) table blocks computed on demand since the last
+ * nemo_counter_reset.  SYNCHRONISES the device. */
+int nemo_solve_table_stats(nemo_ctx *ctx, int32_t *mode, uint64_t *blocks);
 
 /* 6-DoF variant of the solve (code/PredUnlabeledDataset.py:318-347): Adam also moves trans_2d, which
  * enters the camera as extra_trans = trans_2d @ [[1,0,0],[0,1,0]] added to T (:328, lib/MeshUtils.py:107-108).

@@ -17,7 +17,7 @@ EXPORTS = ['nemo_ctx_create', 'nemo_ctx_destroy', 'nemo_last_error', 'nemo_mesh_
            'nemo_interpolate_backward', 'nemo_clutter_score', 'nemo_score_fwd_bwd',
            'nemo_grid_search', 'nemo_grid_prerender', 'nemo_solve', 'nemo_solve6', 'nemo_feature_head', 'nemo_bytes_per_covered_pixel', 'nemo_counter_reset',
            'nemo_counter_read', 'nemo_grid_store_kind', 'nemo_solve_table_capacity',
-           'nemo_solve_last_timing']
+           'nemo_solve_last_timing', 'nemo_solve_table_stats']
 
 
 class NemoHipError(RuntimeError):
@@ -72,6 +72,7 @@ def load():
     lib.nemo_solve_table_capacity.restype = C.c_int64
     lib.nemo_solve_table_capacity.argtypes = [vp]
     lib.nemo_solve_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.nemo_solve_table_stats.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int:

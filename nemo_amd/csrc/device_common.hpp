@@ -20,6 +20,7 @@ constexpr int UST_N = 96;      // floats of workgroup-uniform state kept in LDS
 // camera intermediates of the current iterate [48..82] (kept for the camera backward)
 constexpr int U_R = 0, U_T = 9, U_P = 12, U_M = 16, U_V = 20, U_K = 24, U_TOT = 32, U_CAM = 48;
 constexpr int U_P6 = 84, U_M6 = 86, U_V6 = 88;  // 6-DoF variant: trans_2d and its Adam moments
+constexpr int U_BLK = 30;                     // LAZY solve: table blocks this job computed (a uint32 in a float slot)
 // block totals: [0] loss term, [1..9] dL/dR, [10..12] dL/dT, [13] covered pixels
 constexpr int T_LOSS = 0, T_GR = 1, T_GT = 10, T_NCOV = 13;
 constexpr int MAX_MESHES = 1024;
@@ -31,6 +32,7 @@ constexpr int STAMP_LDS = 0;
 constexpr int LDS_BUDGET = 160 * 1024 / (1024 / NT) - (NT < 1024 ? 512 : 0) - STAMP_LDS;  // the workgroups resident on a CU share its 160 KiB
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
 typedef unsigned long long u64;
 typedef unsigned short us4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));

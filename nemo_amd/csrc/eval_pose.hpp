@@ -15,6 +15,12 @@ namespace {
 // (bank_table_kernel).  The three dot products of a covered pixel are then three 4-byte reads instead of a 512-byte
 // feature row, three bank rows and 3 D multiply-adds: the contraction does not depend on the pose, so it is done once
 // per solve instead of once per Adam step.
+// LAZY (TAB): the table starts EMPTY and is filled on demand, in blocks of (32 consecutive vertices) x (32 consecutive
+// window pixels = one 128-byte line per vertex row).  A bitmap in LDS says which blocks exist; before a wave scores its
+// pixels it computes the blocks they need that are not there yet, itself, on the matrix cores -- the instruction
+// sequence of bank_table_kernel for that block, so the same bits -- stores them, waits for the stores and sets the bits.
+// A step touches about an eighth of a job's blocks and the pose moves slowly: the solve computes a fraction of the
+// table, inside the one kernel.  Two waves may compute the same block at the same time; they store the same values.
 // TAB also turns on the ORDERED rasteriser pass (F <= 2 NT): thread slot i rasterises face L.fc[i].w instead of face i.
 // The caller starts with the identity; on a step with `resort` set the pass counting-sorts the faces by the size of
 // their candidate box (64 bins, LDS atomics) and deals them out so that the 64 lanes of a wave walk candidate loops of
@@ -22,7 +28,7 @@ namespace {
 // in face order the critical wave of a cuboid runs 31-34 iterations against a mean of 17-25.  Which thread rasterises a
 // face is invisible in the results (ds_min on the z-buffer; records and list are indexed by face).
 template <int D, bool PERSP, bool GRAD, bool SCORE, bool RAW = false, bool PRE = false, bool BIG = false, bool TAIL_SYNC = true,
-          bool TAB = false>
+          bool TAB = false, bool LAZY = false>
 __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, const float *__restrict__ feat,
                           const float *__restrict__ clu, EmitOut emit, bool zb_clean = false,
                           const float *__restrict__ vpre = nullptr, const float *__restrict__ tab = nullptr,
@@ -319,10 +325,75 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
           }
         };
         if (home_a) { compact(sA_b, sA_e); compact(sB_b, sB_e); } else { compact(sB_b, sB_e); compact(sA_b, sA_e); }
+        const uint32_t hw32 = ((uint32_t)(P.h * P.w) + 31u) & ~31u;  // row length of the padded table (table_ld)
+        if (LAZY && wcnt > 0) {
+          u64 *const validt = (u64 *)L.finfo + 32;   // per pixel tile: bit c = block (vertex chunk c, tile) exists; the first
+          const uint32_t n_tiles = hw32 >> 5;        // 256 bytes of the area are the sort bins
+          __attribute__((address_space(1))) float *const wtab = (__attribute__((address_space(1))) float *)tab;
+          const int bi = lane & 31, bhalf = lane >> 5;
+          auto compute_block = [&](const uint32_t bc, const uint32_t bt) {   // all 64 lanes; chunk and tile wave-uniform
+            // lane (i, half) feeds feature 8 q + 4 half + c as k-step 4 q + c of both operands (bank_table_kernel's order).
+            // A block is 32 bank rows (one accumulator: the register budget of a 1024-thread workgroup, and finer blocks
+            // waste less: a pixel tile needs some twenty vertices).  The chain of matrix instructions per accumulator is
+            // bank_table_kernel's, so the stored values are bit for bit its values.
+            const gf4p xp = (gf4p)(gfeat + (size_t)min((int)(bt * 32u) + bi, P.h * P.w - 1) * D) + bhalf;
+            const uint32_t col = bt * 32u + (uint32_t)bi;
+            {
+              const gf4p ap = (gf4p)(bank + (size_t)min((int)(bc * 32u) + bi, V - 1) * D) + bhalf;
+              f16v acc;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+              constexpr int PF = 6;   // 16-byte pieces in flight per operand
+              f4 av[PF], xv_[PF];
+#pragma unroll
+              for (int u = 0; u < PF; ++u) { av[u] = ap[2 * u]; xv_[u] = xp[2 * u]; }
+#pragma unroll
+              for (int q = 0; q < D / 8; ++q) {
+                const f4 a = av[q % PF], x = xv_[q % PF];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, x.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, x.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, x.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, x.w, acc, 0, 0, 0);
+                if (q + PF < D / 8) { av[q % PF] = ap[2 * (q + PF)]; xv_[q % PF] = xp[2 * (q + PF)]; }
+                __builtin_amdgcn_sched_barrier(0);
+              }
+              // C/D layout: column = lane & 31 (pixel), row = (r & 3) + 8 (r >> 2) + 4 half; rows past V exist (padded slot)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const uint32_t row = bc * 32u + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * bhalf);
+                wtab[row * hw32 + col] = acc[r];
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the stores are done before the bit says so
+          };
+          for (int e0 = 0; e0 < wcnt; e0 += 64) {
+            const bool on = e0 + lane < wcnt;
+            const uint32_t ent = wl[min(e0 + lane, wcnt - 1)];
+            const us4 fv_ = fc_at<BIG>(L, ent >> 16);
+            const uint32_t tl = (ent & 0xffffu) >> 5;
+            // the (at most three) vertex chunks this entry reads in its tile, as bits; one 8-byte LDS read says which exist
+            const u64 need = on ? ((1ull << (fv_.x >> 5)) | (1ull << (fv_.y >> 5)) | (1ull << (fv_.z >> 5))) : 0ull;
+            u64 missing = need & ~validt[tl];
+            u64 bal = __ballot(missing != 0ull);
+            while (bal) {
+              const int src = __builtin_ctzll(bal);
+              const uint32_t t_s = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)tl, src));
+              const uint32_t m_lo = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)(uint32_t)missing, src));
+              const uint32_t m_hi = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)(uint32_t)(missing >> 32), src));
+              const uint32_t c_s = m_lo ? (uint32_t)__builtin_ctz(m_lo) : 32u + (uint32_t)__builtin_ctz(m_hi);
+              compute_block(c_s, t_s);
+              if (lane == 0) {
+                atomicOr((unsigned long long *)&validt[t_s], 1ull << c_s);
+                atomicAdd((unsigned int *)&L.ust[U_BLK], 1u);
+              }
+              missing = need & ~validt[tl];
+              bal = __ballot(missing != 0ull);
+            }
+          }
+        }
         // The dot products come from the job's table: one lane per entry, the entry's list word, clutter score and three
         // table values are fetched one chunk ahead (unconditionally, with a clamped index: exact wait counts).
         const gf32p gtab = as_global(tab);
-        const uint32_t hw32 = ((uint32_t)(P.h * P.w) + 31u) & ~31u;  // row length of the padded table (table_ld)
         uint32_t ent_c = 0u;
         float cl_c = 0.f, g_c[3] = {0.f, 0.f, 0.f};
         auto fetch = [&](int cb_, uint32_t &ent, float &cl, float (&g)[3]) {

@@ -91,8 +91,10 @@ struct nemo_ctx {
   size_t tab_cap;            // floats
   double env_solve_table_gb;
   int env_table_wpj;         // NEMO_TABLE_WPJ: workgroups per job of bank_table_kernel
+  int env_solve_lazy;        // NEMO_SOLVE_LAZY: 1 (default) the solve kernel fills its tables on demand; 0 bank_table_kernel fills them whole
   hipEvent_t ev_solve[3];    // recorded around the table kernel and the solve kernel of the last table-form call (first slice)
   int ev_solve_valid;
+  int last_solve_mode;       // of the last solve call: 0 streaming, 1 tables filled by bank_table_kernel, 2 tables filled on demand
   int env_grid_records;  // NEMO_GRID_RECORDS: -1 (default) the record store when the dense renders do not fit or G >= 4096; 0 never; 1 whenever it fits
   double env_prerender_map_gb;
   char err[512];
@@ -310,8 +312,8 @@ int nemo_ctx_create(const nemo_config *cfg, nemo_ctx **out) {
   int rc = plan_lds(ctx);
   if (rc != NEMO_OK) { delete ctx; return rc; }
   hipError_t e = hipMalloc((void **)&ctx->d_meshes, sizeof(MeshDesc) * MAX_MESHES);
-  if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_counter, sizeof(u64));
-  if (e == hipSuccess) e = hipMemset(ctx->d_counter, 0, sizeof(u64));
+  if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_counter, 2 * sizeof(u64));   // [0] covered pixel-steps, [1] table blocks computed
+  if (e == hipSuccess) e = hipMemset(ctx->d_counter, 0, 2 * sizeof(u64));
   ctx->adam_cap = 4096;
   for (int i = 0; i < 3; ++i) if (e == hipSuccess) e = hipEventCreate(&ctx->ev_solve[i]);
   if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_adam, sizeof(float) * 2 * ctx->adam_cap);
@@ -336,6 +338,8 @@ int nemo_ctx_create(const nemo_config *cfg, nemo_ctx **out) {
   SET_LDS_B(solve_kernel, 256, false); SET_LDS_B(solve_kernel, 256, true);
   SET_LDS((solve_kernel<128, false, false, true>)); SET_LDS((solve_kernel<128, true, false, true>));
   SET_LDS((solve_kernel<256, false, false, true>)); SET_LDS((solve_kernel<256, true, false, true>));
+  SET_LDS((solve_kernel<128, false, false, true, true>)); SET_LDS((solve_kernel<128, true, false, true, true>));
+  SET_LDS((solve_kernel<256, false, false, true, true>)); SET_LDS((solve_kernel<256, true, false, true, true>));
   SET_LDS_B(interp_bwd_kernel, 128, false); SET_LDS_B(interp_bwd_kernel, 128, true);
   SET_LDS_B(interp_bwd_kernel, 256, false); SET_LDS_B(interp_bwd_kernel, 256, true);
 #undef SET_LDS_B
@@ -359,6 +363,8 @@ int nemo_ctx_create(const nemo_config *cfg, nemo_ctx **out) {
   ctx->env_grid_no_mfma = env_int("NEMO_GRID_NO_MFMA", 0);
   ctx->env_solve_stagger = env_int("NEMO_SOLVE_STAGGER", 0);
   {
+    const char *l_ = getenv("NEMO_SOLVE_LAZY");
+    ctx->env_solve_lazy = l_ ? atoi(l_) : 1;
     const char *w_ = getenv("NEMO_TABLE_WPJ");
     ctx->env_table_wpj = w_ ? std::max(1, std::min(64, atoi(w_))) : 2;
     const char *e_ = getenv("NEMO_SOLVE_TABLE_GB");
@@ -945,6 +951,11 @@ static int launch_solve(nemo_ctx *ctx, const char *who, int32_t N, const int32_t
   if (tab_jobs >= (size_t)N || (tab_jobs >= 256 && d_order)) {
     const int D = ctx->cfg.feat_dim, nt = D == 128 ? CkCfg<128>::NT : CkCfg<256>::NT;
     const size_t lds = (size_t)2 * CK_ROWS * (D + 4) * 4;
+    // lazy tables (NEMO_SOLVE_LAZY, default on): the block bitmap must fit the per-face record area of the LDS plan
+    // behind the 64 sort bins
+    // (one 8-byte word of vertex-chunk bits per pixel tile: at most 64 chunks of 32 = 2048 vertices)
+    const size_t map_bytes = 256 + (size_t)(table_ld((uint32_t)hw) / 32) * 8;
+    const int lazy = (ctx->env_solve_lazy && table_rows((uint32_t)ctx->vmax_seen) <= 2048 && map_bytes <= (size_t)ctx->P.fmax * 16) ? 1 : 0;
     // workgroups per job: a workgroup's prologue (first bank chunk, first feature rows) is exposed, so few, long
     // workgroups -- NEMO_TABLE_WPJ (default 2) -- unless the call has too few jobs to fill the chip with them
     unsigned wpj = (unsigned)ctx->env_table_wpj;
@@ -954,27 +965,32 @@ static int launch_solve(nemo_ctx *ctx, const char *who, int32_t N, const int32_t
       const unsigned nk = (unsigned)std::min<size_t>(tab_jobs, (size_t)N - k0);
       const int32_t *ord = d_order ? d_order + k0 : nullptr;   // (no order: a single slice, slot y = job y)
       if (k0 == 0) hipEventRecord(ctx->ev_solve[0], (hipStream_t)stream);
-      if (D == 128)
+      if (lazy) { /* the solve kernel fills its tables itself, block by block, as its steps ask for them */ }
+      else if (D == 128)
         hipLaunchKernelGGL((bank_table_kernel<128>), dim3(wpj, nk), dim3(nt), lds, (hipStream_t)stream, d_feat, (int)hw,
                            (int)table_ld((uint32_t)hw), d_img_idx, d_mesh_idx, (const MeshDesc *)ctx->d_meshes, ctx->d_tab, tab_stride, ord, (int)N);
       else
         hipLaunchKernelGGL((bank_table_kernel<256>), dim3(wpj, nk), dim3(nt), lds, (hipStream_t)stream, d_feat, (int)hw,
                            (int)table_ld((uint32_t)hw), d_img_idx, d_mesh_idx, (const MeshDesc *)ctx->d_meshes, ctx->d_tab, tab_stride, ord, (int)N);
       if (k0 == 0) hipEventRecord(ctx->ev_solve[1], (hipStream_t)stream);
-#define SOLVE_TAB(DD, PP)                                                                                                   \
-  hipLaunchKernelGGL((solve_kernel<DD, PP, false, true>), dim3(nk), dim3(NT), ctx->lds, (hipStream_t)stream, ctx->P,        \
+#define SOLVE_TAB(DD, PP, LZ)                                                                                               \
+  hipLaunchKernelGGL((solve_kernel<DD, PP, false, true, LZ>), dim3(nk), dim3(NT), ctx->lds, (hipStream_t)stream, ctx->P,    \
                      ctx->d_meshes, d_img_idx, d_mesh_idx, d_feat, d_clu, d_C0, d_theta0, d_trans0, ndof, ctx->d_adam,       \
                      ctx->adam_steps, ctx->beta1, ctx->beta2, ctx->eps, d_pose, d_loss, d_trace, ctx->d_counter, stagger,   \
                      ord, (int)N, d_status, (const float *)ctx->d_tab, tab_stride)
-      if (D == 128) { if (ctx->P.persp) SOLVE_TAB(128, true); else SOLVE_TAB(128, false); }
-      else          { if (ctx->P.persp) SOLVE_TAB(256, true); else SOLVE_TAB(256, false); }
+#define SOLVE_TAB_L(DD, PP) do { if (lazy) SOLVE_TAB(DD, PP, true); else SOLVE_TAB(DD, PP, false); } while (0)
+      if (D == 128) { if (ctx->P.persp) SOLVE_TAB_L(128, true); else SOLVE_TAB_L(128, false); }
+      else          { if (ctx->P.persp) SOLVE_TAB_L(256, true); else SOLVE_TAB_L(256, false); }
+#undef SOLVE_TAB_L
 #undef SOLVE_TAB
       if (k0 == 0) { hipEventRecord(ctx->ev_solve[2], (hipStream_t)stream); ctx->ev_solve_valid = 1; }
     }
+    ctx->last_solve_mode = lazy ? 2 : 1;
     HIP_TRY(ctx, hipGetLastError());
     return NEMO_OK;
   }
   ctx->ev_solve_valid = 0;
+  ctx->last_solve_mode = 0;
   DISPATCH_DP(solve_kernel, dim3(N), ctx->P, ctx->d_meshes, d_img_idx, d_mesh_idx, d_feat, d_clu, d_C0, d_theta0, d_trans0,
               ndof, ctx->d_adam, ctx->adam_steps, ctx->beta1, ctx->beta2, ctx->eps, d_pose, d_loss, d_trace, ctx->d_counter,
               stagger, d_order, (int)N, d_status, (const float *)nullptr, (size_t)0);
@@ -1112,7 +1128,7 @@ int64_t nemo_bytes_per_covered_pixel(const nemo_ctx *ctx) { return ctx ? 4LL * c
 
 int nemo_counter_reset(nemo_ctx *ctx, void *stream) {
   if (!ctx) return fail(nullptr, NEMO_ERR_ARG, "nemo_counter_reset: null ctx");
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_counter, 0, sizeof(u64), (hipStream_t)stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_counter, 0, 2 * sizeof(u64), (hipStream_t)stream));
   return NEMO_OK;
 }
 
@@ -1122,6 +1138,16 @@ int nemo_counter_read(nemo_ctx *ctx, uint64_t *out) {
   u64 v = 0;
   HIP_TRY(ctx, hipMemcpy(&v, ctx->d_counter, sizeof(u64), hipMemcpyDeviceToHost));
   *out = v;
+  return NEMO_OK;
+}
+
+int nemo_solve_table_stats(nemo_ctx *ctx, int32_t *mode, uint64_t *blocks) {
+  if (!ctx || !mode || !blocks) return fail(ctx, NEMO_ERR_ARG, "nemo_solve_table_stats: bad argument");
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  u64 v = 0;
+  HIP_TRY(ctx, hipMemcpy(&v, ctx->d_counter + 1, sizeof(u64), hipMemcpyDeviceToHost));
+  *mode = ctx->last_solve_mode;
+  *blocks = v;
   return NEMO_OK;
 }
 

@@ -170,7 +170,6 @@ __global__ __launch_bounds__(NT, 4) void grid_kernel(KParams P, const MeshDesc *
   }
 }
 
-typedef float f16v __attribute__((ext_vector_type(16)));
 
 // argmin over the grid losses (first minimum, torch.min semantics at
 // code/MeshPoseSolveAll.py:97) -> C0, theta0.
@@ -282,7 +281,7 @@ __global__ void solve_affinity_kernel(int N, int n_meshes, const int32_t *mesh_i
 #ifndef NEMO_RESORT_EVERY
 #define NEMO_RESORT_EVERY 8   // steps between two face sorts of the ordered rasteriser pass (a power of two)
 #endif
-template <int D, bool PERSP, bool BIG, bool TAB = false>
+template <int D, bool PERSP, bool BIG, bool TAB = false, bool LAZY = false>
 __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc *meshes, const int32_t *img_idx,
                                                       const int32_t *mesh_idx, const float *feat, const float *clu,
                                                       const float *C0, const float *theta0, const float *trans0,
@@ -324,6 +323,10 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
   load_world_verts<BIG>(P, L, M);
   if constexpr (TAB) {  // the ordered rasteriser pass (eval_pose) starts in face order
     for (int i = threadIdx.x; i < M.F; i += NT) ((unsigned short *)L.fc)[4 * i + 3] = (unsigned short)i;
+    if constexpr (LAZY) {         // the job's table starts empty: no block exists (bitmap behind the 64 sort bins, eval_pose)
+      const int n_tiles = (((P.h * P.w) + 31) & ~31) >> 5;   // one 8-byte word of vertex-chunk bits per pixel tile
+      for (int i = threadIdx.x; i < n_tiles; i += NT) ((u64 *)L.finfo)[32 + i] = 0ull;
+    }
   }
   loss_constant(P, L, c);
   const bool lead = threadIdx.x == 0;
@@ -335,6 +338,7 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
     L.ust[U_P6] = (ndof == 6 && trans0) ? trans0[2 * n] : 0.f;
     L.ust[U_P6 + 1] = (ndof == 6 && trans0) ? trans0[2 * n + 1] : 0.f;
     L.ust[U_M6] = L.ust[U_M6 + 1] = L.ust[U_V6] = L.ust[U_V6 + 1] = 0.f;
+    *(unsigned int *)&L.ust[U_BLK] = 0u;
     const float ex[3] = {L.ust[U_P6], L.ust[U_P6 + 1], 0.f};
     Cam cam;
     ust_set_camera(L, L.ust + U_P, L.ust[U_P + 3], cam, ndof == 6 ? ex : nullptr);
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
   for (int t = 0; t < steps; ++t) {
     // no closing barrier inside: thread 0 leaves eval_pose with the totals and goes straight on to Adam, the other
     // waves clear the z-buffer meanwhile (the score loop's scratch in that region is dead behind the band barrier)
-    eval_pose<D, PERSP, true, true, false, false, BIG, false, TAB>(P, L, M, f, c, none, true, vreg,
+    eval_pose<D, PERSP, true, true, false, false, BIG, false, TAB, LAZY>(P, L, M, f, c, none, true, vreg,
                                                                      TAB ? tab + (size_t)blockIdx.x * tab_stride : nullptr,
                                                                      TAB && (t & (NEMO_RESORT_EVERY - 1)) == 0);
     fetch_verts();
@@ -430,6 +434,7 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
       status[n] = ok ? 1 : 0;
     }
     if (counter) atomicAdd(counter, cov_total);
+    if (LAZY && counter) atomicAdd(counter + 1, (u64) * (unsigned int *)&L.ust[U_BLK]);
   }
 }
 

@@ -319,6 +319,14 @@ class PoseEngine:
             return None
         return float(a.value), float(b.value)
 
+    def solve_table_stats(self):
+        """(mode, blocks): form of the last solve (0 streaming, 1 whole tables, 2 tables on demand) and the table blocks
+        computed on demand since counter_reset (nemo_solve_table_stats; synchronises)."""
+        import ctypes as C
+        m, b = C.c_int32(), C.c_uint64()
+        _lib.check(self.ctx, self.lib.nemo_solve_table_stats(self.ctx, C.byref(m), C.byref(b)), 'nemo_solve_table_stats')
+        return int(m.value), int(b.value)
+
     def solve_uses_tables(self, n_jobs=1):
         return self.solve_table_capacity() >= max(1, int(n_jobs))
 

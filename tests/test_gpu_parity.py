@@ -1443,8 +1443,8 @@ def test_record_store_random_shapes_equal_dense_renders(monkeypatch, seed):
 
 @pytest.mark.parametrize('D,persp', [(128, False), (128, True), (256, False)])
 def test_solve_tables_against_streaming(oracle, monkeypatch, D, persp):
-    """The two forms of the fused solve on the same jobs: per-job dot-product tables (matrix cores, once per call)
-    against feature rows streamed every step.  Same start, so the first iterates agree to rounding; loss and gradient
+    """The forms of the fused solve on the same jobs: per-job dot-product tables -- filled on demand inside the solve
+    kernel (default) or whole by bank_table_kernel ahead of it, bit-equal -- against feature rows streamed every step.  Same start, so the first iterates agree to rounding; loss and gradient
     of the table form at traced iterates against the oracle (teacher-forced); more jobs than the tables hold go through
     in slices of the launch order and give the same bits as one slice."""
     from nemo_amd.engine import PoseEngine
@@ -1458,19 +1458,33 @@ def test_solve_tables_against_streaming(oracle, monkeypatch, D, persp):
     feats, clus = _dev(sc.feats), _dev(sc.clus)
     out = {}
     stride_gb = (-(-sc.verts.shape[0] // 64) * 64) * (-(-(sc.cfg.h * sc.cfg.w) // 32) * 32) * 4 / 2 ** 30   # one job's (padded) table slot
-    for mode, gb in (('tables', None), ('streaming', '0'), ('sliced', '%.6f' % (260 * stride_gb))):
+    n_blocks = -(-sc.verts.shape[0] // 32) * -(-(sc.cfg.h * sc.cfg.w) // 32)   # (32 vertices x 32 pixels) blocks of one job's table
+    for mode, gb, lazy in (('tables', None, None), ('whole', None, '0'), ('streaming', '0', None),
+                           ('sliced', '%.6f' % (260 * stride_gb), None)):
         if gb is None:
             monkeypatch.delenv('NEMO_SOLVE_TABLE_GB', raising=False)
         else:
             monkeypatch.setenv('NEMO_SOLVE_TABLE_GB', gb)
+        if lazy is None:
+            monkeypatch.delenv('NEMO_SOLVE_LAZY', raising=False)
+        else:
+            monkeypatch.setenv('NEMO_SOLVE_LAZY', lazy)
         eng = PoseEngine(sc.geo.S, (sc.geo.h, sc.geo.w), D, perspective_correct=persp)
         eng.register_mesh(sc.verts, sc.faces, sc.bank)
         eng.set_schedule(40)
+        eng.counter_reset()
         pose, loss, tr = eng.solve(feats, clus, _dev(C0), _dev(th0), img_idx=_dev(img, torch.int32), want_trace=True)
         cap = eng.solve_table_capacity()
-        assert (cap >= n) if mode == 'tables' else (cap == 0) if mode == 'streaming' else (256 <= cap < n)
+        assert (cap >= n) if mode in ('tables', 'whole') else (cap == 0) if mode == 'streaming' else (256 <= cap < n)
+        form, blocks = eng.solve_table_stats()
+        assert form == {'tables': 2, 'whole': 1, 'streaming': 0, 'sliced': 2}[mode]
+        # tables filled on demand: something was computed, and far from everything
+        assert (0 < blocks < 0.6 * n * n_blocks) if form == 2 else blocks == 0
         out[mode] = (pose.cpu().numpy(), loss.cpu().numpy(), tr.cpu().numpy())
     assert np.array_equal(out['sliced'][0], out['tables'][0]) and np.array_equal(out['sliced'][2], out['tables'][2])
+    # blocks computed on demand inside the solve kernel hold the bits bank_table_kernel writes: same trajectories
+    for k in range(3):
+        assert np.array_equal(out['whole'][k], out['tables'][k])
     tt, ts = out['tables'][2], out['streaming'][2]
     # (C, theta) of the first iterates: Adam's first steps are lr * g / (|g| + eps) per component, which turns the last
     # bits of a small gradient component into ~1e-5 of the parameter
