@@ -248,7 +248,8 @@ def launch_ranks(n_gpus, argv):
 
 
 PMC_FILE = 'profiles/r03_pmc_traffic.json'            # streaming form of the solve
-PMC_TABLES_FILE = 'profiles/r03_pmc_solve_tables.json'  # tables form: bank_table_kernel + solve_kernel<TAB>
+PMC_TABLES_FILE = 'profiles/r03_pmc_solve_tables.json'  # whole tables: bank_table_kernel + solve_kernel<TAB>
+PMC_LAZY_FILE = 'profiles/r03_pmc_solve_lazy.json'      # tables on demand: solve_kernel<TAB, LAZY>
 TABLE_BYTES_PER_COVERED_PIXEL_STEP = 16  # tables form: three 4-byte dot products + the 4-byte clutter score
 
 
@@ -340,10 +341,13 @@ def main():
     nd.fence(dev)
     dt = nd.max_over_ranks(time.perf_counter() - t0, dev)
 
-    # ---- the solve timed alone.  Tables form (the default when the reserved workspace holds the tables): two kernels,
-    # bank_table_kernel (all feature-row x bank-row dot products of a job, once, on the matrix cores) and
-    # solve_kernel<TAB> (the 300 steps); the library records HIP events around both on the launch stream
-    # (nemo_solve_last_timing).  Streaming form: the one solve_kernel, torch events on the same (current) stream.
+    # ---- the solve timed alone, on the launch stream.  Three forms (include/nemo_hip.h "TABLES / STREAMING"):
+    #  2 tables on demand (default): ONE kernel, solve_kernel<TAB, LAZY> -- its waves compute the (32 vertices x 32
+    #    pixels) blocks of feature-row x bank-row dot products their pixels need, on the matrix cores, the first time
+    #    they need them, and every step reads three floats per covered pixel;
+    #  1 whole tables (NEMO_SOLVE_LAZY=0): bank_table_kernel computes every block of every job, then solve_kernel<TAB>;
+    #  0 streaming (no table workspace): solve_kernel contracts the feature rows itself in every step.
+    # The library records HIP events around its kernels (nemo_solve_last_timing); torch events bracket the whole call.
     clu = eng.clutter_score(wl.feats, wl.clutter)
     C0, th0, _, _ = eng.grid_search(wl.feats, clu, solver.grid_C, solver.grid_theta, mesh_idx=wl.mesh_idx,
                                     grid_idx=wl.mesh_idx)
@@ -361,44 +365,68 @@ def main():
     torch.cuda.synchronize(dev)
     solve_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     cov_steps = eng.counter_read() / reps  # covered pixel-steps of one solve launch
+    form, blocks = eng.solve_table_stats()
+    blocks /= reps                         # table blocks computed on demand per launch (form 2)
     stream_bytes = cov_steps * eng.bytes_per_covered_pixel()   # n_cov (4 D + 4) per job-step
     working_set = float(min(args.images, 256)) * stream_bytes / max(1, args.images * solver.cfg.total_epochs)
     extra = {}
-    if all(t is not None for t in tabs):
-        table_ms = float(np.mean([t[0] for t in tabs]))
+    hw = eng.h * eng.w
+    verts = np.asarray([int(v.shape[0]) for v, _, _ in eng._keep], dtype=np.float64)
+    whole_flops = float((2.0 * verts[wl.mesh_idx.cpu().numpy()] * hw * eng.D).sum())   # 2 V hw D per job
+    if form in (1, 2) and all(t is not None for t in tabs):
+        table_ms = float(np.mean([t[0] for t in tabs])) if form == 1 else 0.0
         loop_ms = float(np.mean([t[1] for t in tabs]))
-        hw = eng.h * eng.w
-        verts = np.asarray([int(v.shape[0]) for v, _, _ in eng._keep], dtype=np.float64)
-        flops = float((2.0 * verts[wl.mesh_idx.cpu().numpy()] * hw * eng.D).sum())   # 2 V hw D per job
         loop_bytes = cov_steps * TABLE_BYTES_PER_COVERED_PIXEL_STEP
-        per_loop = _pmc(PMC_TABLES_FILE, 'solve_kernel', 'hbm_bytes_per_covered_pixel_step')
-        per_tab = _pmc(PMC_TABLES_FILE, 'bank_table_kernel', 'hbm_bytes_per_job')
-        tf = flops / (table_ms * 1e-3) / 1e12
-        roof = {'bound': 'hbm', 'achieved': loop_bytes / (loop_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': loop_bytes / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        # a block on demand: 32 bank rows and 32 feature rows read, 32 x 32 dot products written
+        block_bytes = blocks * (64.0 * eng.D * 4 + 32 * 32 * 4)
+        block_flops = blocks * 2.0 * 32 * 32 * eng.D
+        pmc_file = PMC_LAZY_FILE if form == 2 else PMC_TABLES_FILE
+        per_loop = _pmc(pmc_file, 'solve_kernel', 'hbm_bytes_per_covered_pixel_step')
+        alg = loop_bytes + (block_bytes if form == 2 else 0.0)
+        roof = {'bound': 'hbm', 'achieved': alg / (loop_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': alg / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 'traffic': None if per_loop is None else per_loop * cov_steps,
-                'kernel': 'solve_kernel<TAB>', 'kernel_ms': loop_ms, 'algorithmic_bytes_per_launch': loop_bytes,
+                'kernel': 'solve_kernel<TAB, LAZY>' if form == 2 else 'solve_kernel<TAB>', 'kernel_ms': loop_ms,
+                'algorithmic_bytes_per_launch': alg,
                 'bytes_per_covered_pixel_step': TABLE_BYTES_PER_COVERED_PIXEL_STEP,
                 'covered_pixel_steps_per_launch': cov_steps,
-                'traffic_source': f'scaled from the committed PMC pass {PMC_TABLES_FILE} (not read during this run)',
-                'note': 'the dominant kernel by time.  In the tables form it is NOT bound by HBM (nor by the matrix cores): its '
-                        '300 steps project, rasterise, list and score a job per step on the vector ALUs and the LDS (SQ '
-                        'counters: vector ALUs issuing about two thirds of the time, profiles/r03_sq_solve_tables.txt); per '
-                        'covered pixel and step it reads 16 bytes where the streaming form read 516.  `traffic` above '
-                        '`algorithmic bytes`: a 4-byte table read fetches a cache line'}
-        extra['roofline_table'] = {
-            'bound': 'mfma', 'achieved': tf, 'peak': MFMA_FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / MFMA_FP32_PEAK_TFLOPS,
-            'traffic': None if per_tab is None else per_tab * args.images, 'kernel': 'bank_table_kernel', 'kernel_ms': table_ms,
-            'flops_per_launch': flops, 'dtype': 'f32',
-            'note': 'second kernel of the solve: [V x D] . [D x h w] per job on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains), '
-                    '2 V h w D flops per job; its traffic is the table it writes (V h w 4 bytes per job) plus the maps it reads once'}
+                'traffic_source': f'scaled from the committed PMC pass {pmc_file} (not read during this run)',
+                'note': 'the dominant kernel by time.  It is NOT bound by HBM (nor by the matrix cores): its 300 steps project, '
+                        'rasterise, compact and score a job per step on the vector ALUs and the LDS (SQ counters: '
+                        'profiles/r03_sq_solve_lazy.txt); per covered pixel and step it reads 16 bytes where the streaming '
+                        'form read 516'
+                        + ('; algorithmic bytes = those 16 x covered pixel-steps + 36 KB per table block computed on demand '
+                           '(32 bank rows + 32 feature rows read, 4 KB written)' if form == 2 else '')
+                        + '.  `traffic` above `algorithmic bytes`: a 4-byte table read fetches a cache line'}
+        if form == 2:
+            extra['roofline_table'] = {
+                'bound': 'mfma', 'achieved': None, 'peak': MFMA_FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': None,
+                'kernel': 'solve_kernel<TAB, LAZY> (its matrix-core part; not timed apart from the kernel)',
+                'blocks_per_launch': blocks, 'blocks_per_job': blocks / max(1, args.images),
+                'flops_per_launch': block_flops, 'whole_table_flops_per_launch': whole_flops,
+                'fraction_of_whole_table': block_flops / whole_flops, 'dtype': 'f32',
+                'note': 'tables on demand: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains) on (32 vertices x 32 pixels) blocks, '
+                        'computed by the wave that needs them; NEMO_SOLVE_LAZY=0 computes every block of every job in '
+                        'bank_table_kernel instead (2 V h w D flops per job; 22 ms = 0.65 of the fp32 matrix peak, '
+                        'profiles/r03_bench_whole_tables.json)'}
+        else:
+            per_tab = _pmc(PMC_TABLES_FILE, 'bank_table_kernel', 'hbm_bytes_per_job')
+            tf = whole_flops / (table_ms * 1e-3) / 1e12
+            extra['roofline_table'] = {
+                'bound': 'mfma', 'achieved': tf, 'peak': MFMA_FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / MFMA_FP32_PEAK_TFLOPS,
+                'traffic': None if per_tab is None else per_tab * args.images, 'kernel': 'bank_table_kernel', 'kernel_ms': table_ms,
+                'flops_per_launch': whole_flops, 'dtype': 'f32',
+                'note': 'second kernel of the solve: [V x D] . [D x h w] per job on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains), '
+                        '2 V h w D flops per job; its traffic is the table it writes (V h w 4 bytes per job) plus the maps it reads once'}
         extra['roofline_streaming_equivalent'] = {
             'bound': 'hbm', 'achieved': stream_bytes / ((table_ms + loop_ms) * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': stream_bytes / ((table_ms + loop_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 'kernel': 'bank_table_kernel + solve_kernel<TAB>',
+            'frac': stream_bytes / ((table_ms + loop_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            'kernel': 'solve_kernel<TAB, LAZY>' if form == 2 else 'bank_table_kernel + solve_kernel<TAB>',
             'kernel_ms': table_ms + loop_ms, 'algorithmic_bytes_per_launch': stream_bytes,
             'note': 'continuity with rounds 1-2 (frac 0.63-0.65): SURVEY 8(d)\'s per-unit figure, n_cov (4 D + 4) bytes per job-step '
-                    '-- what the streaming formulation of the solve must move -- divided by the time of the two kernels that '
-                    'replace it.  Above 1: those bytes are no longer moved; the contraction they fed is done once per solve'}
+                    '-- what the streaming formulation of the solve must move -- divided by the time of the kernel(s) that '
+                    'replace it.  Above 1: those bytes are no longer moved; the contraction they fed is done once per '
+                    '(vertex, pixel) block instead of once per step'}
     else:
         achieved = stream_bytes / (solve_ms * 1e-3) / 1e9
         roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -410,7 +438,7 @@ def main():
                 # Infinity Cache: FETCH_SIZE counts L2 misses whether the Infinity Cache or HBM serves them,
                 # so `frac` (algorithmic bytes / time) is an upper bound on DRAM utilisation
                 'working_set_bytes': working_set, 'infinity_cache_bytes': 256 * 2 ** 20}
-    roof['solve_form'] = 'tables' if extra else 'streaming'
+    roof['solve_form'] = {0: 'streaming', 1: 'whole tables', 2: 'tables on demand'}.get(form, str(form))
     roof['solve_ms'] = solve_ms
 
     if rank == 0:

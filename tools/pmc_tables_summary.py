@@ -18,9 +18,12 @@ images = int(sys.argv[5])
 out = {'command': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/prof_solve.py --images %d --steps 300 --reps 1' % images,
        'note': 'bytes; FETCH_SIZE x 1024 x 2 (gfx950 correction), WRITE_SIZE x 1024; one launch of each kernel', 'covered_pixel_steps': cov, 'images': images}
 for k in ('solve_kernel', 'bank_table_kernel'):
+    if k not in f:   # tables on demand: no bank_table_kernel
+        continue
     fb, wb = f[k] * 2048, w.get(k, 0.0) * 1024
     out[k] = {'calls': fc[k], 'fetch_bytes': fb, 'write_bytes': wb, 'hbm_bytes': fb + wb}
 out['solve_kernel']['hbm_bytes_per_covered_pixel_step'] = out['solve_kernel']['hbm_bytes'] / cov
-out['bank_table_kernel']['hbm_bytes_per_job'] = out['bank_table_kernel']['hbm_bytes'] / images
+if 'bank_table_kernel' in out:
+    out['bank_table_kernel']['hbm_bytes_per_job'] = out['bank_table_kernel']['hbm_bytes'] / images
 json.dump(out, open(sys.argv[4], 'w'), indent=1)
 print(json.dumps(out, indent=1))

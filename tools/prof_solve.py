@@ -52,6 +52,11 @@ for r in range(args.reps):
     print(f'solve: {args.images} images x {args.steps} steps: {dt*1e3:.2f} ms, {dt*1e6/args.steps:.1f} us/step, '
           f'cov/step/img {cov/args.steps/args.images:.0f}, alg GB/s {cov*eng.bytes_per_covered_pixel()/dt/1e9:.0f}')
     print(f'  covered pixel-steps {cov}')
+    if hasattr(eng.lib, 'nemo_solve_table_stats'):
+        form, blocks = eng.solve_table_stats()
+        nb = -(-max(int(v.shape[0]) for v, _, _ in eng._keep) // 32) * -(-(eng.h * eng.w) // 32)
+        print(f'  solve form {form} (0 streaming, 1 whole tables, 2 on demand); table blocks computed on demand: {blocks} = '
+              f'{blocks / args.images:.0f} per job of {nb} ({100.0 * blocks / args.images / nb:.1f} %)')
     tl = eng.solve_last_timing() if hasattr(eng.lib, 'nemo_solve_last_timing') else None
     if tl:
         print(f'  tables form: bank_table_kernel {tl[0]:.2f} ms, solve_kernel {tl[1]:.2f} ms = {tl[1]*1e3/args.steps/((args.images+255)//256):.2f} us per job-step')

@@ -23,6 +23,7 @@ for step in "$@"; do
               done
               python3 tools/pmc_tables_summary.py $O/pmct_FETCH_SIZE $O/pmct_WRITE_SIZE $O/pmct_FETCH_SIZE.log $O/pmc_solve_tables.json 1024 || exit 1 ;;
     sq_tables) bash tools/pmc_sq.sh "" r03tab > $O/sq_solve_tables.txt 2>&1 || exit 1 ;;
+    bench_whole) NEMO_SOLVE_LAZY=0 timeout -k 10 400 python3 bench.py --from-files-images 0 --no-cpu-baseline > $O/bench_whole_tables.json 2> $O/bench_whole.err || exit 1 ;;
     pmc_dense12) for c in FETCH_SIZE WRITE_SIZE; do
                 timeout -s KILL 200 rocprofv3 --pmc $c --output-format csv -d $O/pmcd12_$c -- python3 tools/bench_configs.py dense12 > $O/pmcd12_$c.log 2>&1 || exit 1
               done
