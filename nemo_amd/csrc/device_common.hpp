@@ -33,6 +33,14 @@ constexpr int LDS_BUDGET = 160 * 1024 / (1024 / NT) - (NT < 1024 ? 512 : 0) - ST
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
+
+// Columns of a row of the solve's dot-product tables (bank_table_kernel, eval_pose<TAB>): the window is cut into
+// patches of 4 rows x 8 columns; column c of a table row = patch (c >> 5), position (c & 31) = 8 (row & 3) + (col & 7)
+// inside it; patches row-major, table_tpr(w) per patch row.  A (32 vertices x one patch) block is what the matrix cores
+// produce at a time, and a face's pixels -- a compact 2-D neighbourhood -- fall into far fewer patches than into runs of
+// 32 consecutive pixels of an image row (blocks computed on demand per job: 0.57 of the row-run layout).
+__host__ __device__ inline uint32_t table_tpr(uint32_t w) { return (w + 7u) >> 3; }
+__host__ __device__ inline uint32_t table_ld(uint32_t h, uint32_t w) { return ((h + 3u) >> 2) * table_tpr(w) * 32u; }
 typedef unsigned long long u64;
 typedef unsigned short us4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));

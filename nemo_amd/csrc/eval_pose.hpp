@@ -210,7 +210,8 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       // face's three bank rows, by vertex slot)
       auto phase_b = [&](const uint32_t ent_b, const float cl, const float g0, const float g1, const float g2) {
           const int p = (int)(ent_b & 0xffffu), f = (int)(ent_b >> 16);
-          const int pi = (int)__umulhi((unsigned)p, P.w_magic), pj = p - pi * P.w;
+          // window row / column of the pixel (TAB: the list word holds them, 8 bits each)
+          const int pi = TAB ? (p >> 8) : (int)__umulhi((unsigned)p, P.w_magic), pj = TAB ? (p & 0xff) : p - pi * P.w;
           const int a = S - 1 - (pj + P.c0), b = S - 1 - (pi + P.r0);
           const us4 fv_ = fc_at<BIG>(L, f);
           const int i0 = fv_.x, i1 = fv_.y, i2 = fv_.z;
@@ -293,7 +294,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
       if constexpr (TAB) {
         // TAB: there is no workgroup-wide list.  `ntot` is the number of z-buffer entries of the band; a wave owns
         // contiguous runs of entries (below) and compacts the covered ones IN PLACE (64 keys are read,
-        // then their list words -- face << 16 | window pixel, in entry order -- overwrite the low end of the wave's
+        // then their list words -- face << 16 | window row << 8 | window column, in entry order -- overwrite the low end of the wave's
         // own segment: a write never reaches an entry that is still to be read, and the LDS operations of a wave
         // complete in order) and scores them straight away: no count pass, no scan, no fill, no barrier between the
         // rasteriser's and the end of the score.  Entry order is row-major over the object's box, so every float sum
@@ -320,23 +321,28 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
             if (col < 0) { --row; col += tab_bw; }
             if (col >= tab_bw) { ++row; col -= tab_bw; }
             const int a = tab_a_lo + col, b = tab_bb + row;
-            if (cov) wl[wcnt + pre] = (f << 16) | (uint32_t)((S - 1 - b - P.r0) * P.w + (S - 1 - a - P.c0));
+            if (cov) wl[wcnt + pre] = (f << 16) | (uint32_t)((S - 1 - b - P.r0) << 8) | (uint32_t)(S - 1 - a - P.c0);
             wcnt += __builtin_popcountll(bal);
           }
         };
         if (home_a) { compact(sA_b, sA_e); compact(sB_b, sB_e); } else { compact(sB_b, sB_e); compact(sA_b, sA_e); }
-        const uint32_t hw32 = ((uint32_t)(P.h * P.w) + 31u) & ~31u;  // row length of the padded table (table_ld)
+        const uint32_t tpr = table_tpr((uint32_t)P.w), hw32 = table_ld((uint32_t)P.h, (uint32_t)P.w);  // pixel patches per patch row; row length of the table
+        // column of a list word's pixel in a table row, and its patch (device_common.hpp, table_ld)
+        auto patch_of = [&](uint32_t ent) { return ((ent >> 10) & 63u) * tpr + ((ent & 0xffu) >> 3); };
+        auto col_of = [&](uint32_t ent) { return patch_of(ent) * 32u + ((ent >> 5) & 0x18u) + (ent & 7u); };
         if (LAZY && wcnt > 0) {
           u64 *const validt = (u64 *)L.finfo + 32;   // per pixel tile: bit c = block (vertex chunk c, tile) exists; the first
           const uint32_t n_tiles = hw32 >> 5;        // 256 bytes of the area are the sort bins
           __attribute__((address_space(1))) float *const wtab = (__attribute__((address_space(1))) float *)tab;
           const int bi = lane & 31, bhalf = lane >> 5;
-          auto compute_block = [&](const uint32_t bc, const uint32_t bt) {   // all 64 lanes; chunk and tile wave-uniform
+          auto compute_block = [&](const uint32_t bc, const uint32_t bt, const uint32_t ti, const uint32_t tj) {   // all 64 lanes; chunk and patch bt = (ti, tj) wave-uniform
             // lane (i, half) feeds feature 8 q + 4 half + c as k-step 4 q + c of both operands (bank_table_kernel's order).
             // A block is 32 bank rows (one accumulator: the register budget of a 1024-thread workgroup, and finer blocks
             // waste less: a pixel tile needs some twenty vertices).  The chain of matrix instructions per accumulator is
             // bank_table_kernel's, so the stored values are bit for bit its values.
-            const gf4p xp = (gf4p)(gfeat + (size_t)min((int)(bt * 32u) + bi, P.h * P.w - 1) * D) + bhalf;
+            // lane bi of a half = position bi of the patch (row bi >> 3, column bi & 7; past the window: its edge, padding)
+            const int xpix = min((int)(4u * ti) + (bi >> 3), P.h - 1) * P.w + min((int)(8u * tj) + (bi & 7), P.w - 1);
+            const gf4p xp = (gf4p)(gfeat + (size_t)xpix * D) + bhalf;
             const uint32_t col = bt * 32u + (uint32_t)bi;
             {
               const gf4p ap = (gf4p)(bank + (size_t)min((int)(bc * 32u) + bi, V - 1) * D) + bhalf;
@@ -370,7 +376,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
             const bool on = e0 + lane < wcnt;
             const uint32_t ent = wl[min(e0 + lane, wcnt - 1)];
             const us4 fv_ = fc_at<BIG>(L, ent >> 16);
-            const uint32_t tl = (ent & 0xffffu) >> 5;
+            const uint32_t tl = patch_of(ent);
             // the (at most three) vertex chunks this entry reads in its tile, as bits; one 8-byte LDS read says which exist
             const u64 need = on ? ((1ull << (fv_.x >> 5)) | (1ull << (fv_.y >> 5)) | (1ull << (fv_.z >> 5))) : 0ull;
             u64 missing = need & ~validt[tl];
@@ -381,7 +387,8 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
               const uint32_t m_lo = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)(uint32_t)missing, src));
               const uint32_t m_hi = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)(uint32_t)(missing >> 32), src));
               const uint32_t c_s = m_lo ? (uint32_t)__builtin_ctz(m_lo) : 32u + (uint32_t)__builtin_ctz(m_hi);
-              compute_block(c_s, t_s);
+              const uint32_t e_s = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)ent, src));
+              compute_block(c_s, t_s, (e_s >> 10) & 63u, (e_s & 0xffu) >> 3);
               if (lane == 0) {
                 atomicOr((unsigned long long *)&validt[t_s], 1ull << c_s);
                 atomicAdd((unsigned int *)&L.ust[U_BLK], 1u);
@@ -398,8 +405,8 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
         float cl_c = 0.f, g_c[3] = {0.f, 0.f, 0.f};
         auto fetch = [&](int cb_, uint32_t &ent, float &cl, float (&g)[3]) {
           ent = wl[min(cb_ + lane, wcnt - 1)];
-          const uint32_t px = ent & 0xffffu;
-          cl = (P.clutter && clu) ? gclu[px] : 0.0f;
+          const uint32_t px = col_of(ent);
+          cl = (P.clutter && clu) ? gclu[((ent >> 8) & 0xffu) * (uint32_t)P.w + (ent & 0xffu)] : 0.0f;
           const us4 fv_ = fc_at<BIG>(L, ent >> 16);
           g[0] = gtab[(uint32_t)fv_.x * hw32 + px]; g[1] = gtab[(uint32_t)fv_.y * hw32 + px]; g[2] = gtab[(uint32_t)fv_.z * hw32 + px];
         };

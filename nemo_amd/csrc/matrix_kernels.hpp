@@ -1010,22 +1010,22 @@ __global__ __launch_bounds__(CkCfg<D>::NT) void clutter_kernel(const float *__re
   }
 }
 
-// Geometry of a padded table slot (see bank_table_kernel): row length and row count.
-__host__ __device__ inline uint32_t table_ld(uint32_t hw) { return (hw + 31u) & ~31u; }
+// Geometry of a padded table slot (see bank_table_kernel): row count (row length: table_ld, device_common.hpp).
 __host__ __device__ inline uint32_t table_rows(uint32_t vmax) { return (vmax + (uint32_t)CK_ROWS - 1u) / (uint32_t)CK_ROWS * (uint32_t)CK_ROWS; }
 
 // Per-job table of ALL feature-row x bank-row dot products: tab[n][v][p] = <bank_m(n)[v], feat_img(n)[p]>, f32
 // [N][tab_stride / hw rows][hw].  The three dot products the solve needs per covered pixel and Adam step do not depend
 // on the pose, so nemo_solve computes them once here -- a [V x D] . [D x hw] product per job on the fp32 matrix cores,
 // clutter_kernel's structure with the accumulators stored instead of maximised -- and its 300 steps read three floats
-// per covered pixel (eval_pose<TAB>).  Vertex-major rows: a lane owns a pixel column, so a stored accumulator row is 32
-// consecutive pixels (128 bytes), and the pixels of a face and of its neighbours share the table's cache lines.
+// per covered pixel (eval_pose<TAB>).  Vertex-major rows: a lane owns a pixel column, so a stored accumulator row is the
+// 32 pixels of one 4-row x 8-column patch of the window (128 bytes; column order: table_ld, device_common.hpp), and the
+// pixels of a face and of its neighbours share the table's cache lines.
 // Grid: (workgroups per job, jobs of the launch); slot y of the table belongs to the job workgroup y of the solve runs.
-// A slot is PADDED -- rows of ld = hw rounded up to 32 floats, a multiple of CK_ROWS rows (table_ld / table_rows) -- so
+// A slot is PADDED -- rows of ld = 32 floats per pixel patch, a multiple of CK_ROWS rows (table_ld / table_rows) -- so
 // that every store of the kernel is unconditional: a predicated store costs a branch around it and, behind a branch, the
 // compiler can no longer count outstanding memory operations and waits for all of them.
 template <int D>
-__global__ __launch_bounds__(CkCfg<D>::NT) void bank_table_kernel(const float *__restrict__ feat, int hw, int ld,
+__global__ __launch_bounds__(CkCfg<D>::NT) void bank_table_kernel(const float *__restrict__ feat, int hw, int ld, int w,
                                                                   const int32_t *img_idx, const int32_t *mesh_idx,
                                                                   const MeshDesc *meshes, float *__restrict__ tab,
                                                                   size_t tab_stride, const int32_t *order, int N) {
@@ -1044,7 +1044,8 @@ __global__ __launch_bounds__(CkCfg<D>::NT) void bank_table_kernel(const float *_
   const float *fimg = feat + (size_t)(img_idx ? img_idx[n] : n) * hw * D;
   __attribute__((address_space(1))) float *gout = (__attribute__((address_space(1))) float *)(tab + (size_t)blockIdx.y * tab_stride);
   const int nchunks = (K + CK_ROWS - 1) / CK_ROWS;
-  const int ntiles = (hw + 31) / 32;
+  const int ntiles = ld / 32;   // pixel patches (4 rows x 8 columns of the window), row-major
+  const int tpr = (int)table_tpr((uint32_t)w), h = hw / w;
   f4 st[NS];
   auto stage_load = [&](int c) {
 #pragma unroll
@@ -1061,7 +1062,10 @@ __global__ __launch_bounds__(CkCfg<D>::NT) void bank_table_kernel(const float *_
     }
   };
   auto load_x = [&](int tile, f4(&x)[D / 8]) {
-    const int pix = min(tile * 32 + i, hw - 1);
+    // lane i of a half = position i of the patch: row i >> 3, column i & 7 (columns past the window repeat its edge:
+    // their table entries are padding)
+    const int ti = tile / tpr, tj = tile - ti * tpr;
+    const int pix = min(4 * ti + (i >> 3), h - 1) * w + min(8 * tj + (i & 7), w - 1);
     const f4 *xp = (const f4 *)(fimg + (size_t)pix * D) + half;
 #pragma unroll
     for (int q = 0; q < D / 8; ++q) x[q] = __builtin_nontemporal_load(xp + 2 * q);

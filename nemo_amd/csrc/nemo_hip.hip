@@ -124,7 +124,7 @@ static int hip_fail(nemo_ctx *ctx, hipError_t e, const char *what) {
 // floats per job in the solve's dot-product tables (padded slot, matrix_kernels.hpp); 0 before any mesh is registered
 static size_t table_stride(const nemo_ctx *ctx) {
   if (ctx->vmax_seen <= 0) return 0;
-  return (size_t)table_rows((uint32_t)ctx->vmax_seen) * table_ld((uint32_t)(ctx->cfg.win_h * ctx->cfg.win_w));
+  return (size_t)table_rows((uint32_t)ctx->vmax_seen) * table_ld((uint32_t)ctx->cfg.win_h, (uint32_t)ctx->cfg.win_w);
 }
 
 static int plan_lds(nemo_ctx *ctx) {
@@ -947,20 +947,22 @@ static int launch_solve(nemo_ctx *ctx, const char *who, int32_t N, const int32_t
   // large (BIG) meshes.  A call with more jobs than the tables hold goes through in slices of the launch order (which
   // then exists: such a call has more than 64 jobs): tables for a slice, then its solve, on the one stream.
   const size_t hw = (size_t)ctx->cfg.win_h * ctx->cfg.win_w, tab_stride = table_stride(ctx);
-  const size_t tab_jobs = (!ctx->P.big && ctx->d_tab && tab_stride > 0) ? ctx->tab_cap / tab_stride : 0;
+  // (the tables form packs a covered pixel's window row and column into 8 bits each)
+  const size_t tab_jobs = (!ctx->P.big && ctx->d_tab && tab_stride > 0 && ctx->cfg.win_h <= 256 && ctx->cfg.win_w <= 256) ? ctx->tab_cap / tab_stride : 0;
   if (tab_jobs >= (size_t)N || (tab_jobs >= 256 && d_order)) {
     const int D = ctx->cfg.feat_dim, nt = D == 128 ? CkCfg<128>::NT : CkCfg<256>::NT;
     const size_t lds = (size_t)2 * CK_ROWS * (D + 4) * 4;
     // lazy tables (NEMO_SOLVE_LAZY, default on): the block bitmap must fit the per-face record area of the LDS plan
     // behind the 64 sort bins
     // (one 8-byte word of vertex-chunk bits per pixel tile: at most 64 chunks of 32 = 2048 vertices)
-    const size_t map_bytes = 256 + (size_t)(table_ld((uint32_t)hw) / 32) * 8;
+    const uint32_t tab_ld = table_ld((uint32_t)ctx->cfg.win_h, (uint32_t)ctx->cfg.win_w);
+    const size_t map_bytes = 256 + (size_t)(tab_ld / 32) * 8;
     const int lazy = (ctx->env_solve_lazy && table_rows((uint32_t)ctx->vmax_seen) <= 2048 && map_bytes <= (size_t)ctx->P.fmax * 16) ? 1 : 0;
     // workgroups per job: a workgroup's prologue (first bank chunk, first feature rows) is exposed, so few, long
     // workgroups -- NEMO_TABLE_WPJ (default 2) -- unless the call has too few jobs to fill the chip with them
     unsigned wpj = (unsigned)ctx->env_table_wpj;
     while ((size_t)wpj * (size_t)std::min<size_t>(tab_jobs, (size_t)N) < 512 && wpj < 8) wpj *= 2;
-    wpj = (unsigned)std::min<size_t>(wpj, ((hw + 31) / 32 + (nt / 64) - 1) / (nt / 64));
+    wpj = (unsigned)std::min<size_t>(wpj, (tab_ld / 32 + (nt / 64) - 1) / (nt / 64));
     for (size_t k0 = 0; k0 < (size_t)N; k0 += tab_jobs) {
       const unsigned nk = (unsigned)std::min<size_t>(tab_jobs, (size_t)N - k0);
       const int32_t *ord = d_order ? d_order + k0 : nullptr;   // (no order: a single slice, slot y = job y)
@@ -968,10 +970,10 @@ static int launch_solve(nemo_ctx *ctx, const char *who, int32_t N, const int32_t
       if (lazy) { /* the solve kernel fills its tables itself, block by block, as its steps ask for them */ }
       else if (D == 128)
         hipLaunchKernelGGL((bank_table_kernel<128>), dim3(wpj, nk), dim3(nt), lds, (hipStream_t)stream, d_feat, (int)hw,
-                           (int)table_ld((uint32_t)hw), d_img_idx, d_mesh_idx, (const MeshDesc *)ctx->d_meshes, ctx->d_tab, tab_stride, ord, (int)N);
+                           (int)tab_ld, ctx->cfg.win_w, d_img_idx, d_mesh_idx, (const MeshDesc *)ctx->d_meshes, ctx->d_tab, tab_stride, ord, (int)N);
       else
         hipLaunchKernelGGL((bank_table_kernel<256>), dim3(wpj, nk), dim3(nt), lds, (hipStream_t)stream, d_feat, (int)hw,
-                           (int)table_ld((uint32_t)hw), d_img_idx, d_mesh_idx, (const MeshDesc *)ctx->d_meshes, ctx->d_tab, tab_stride, ord, (int)N);
+                           (int)tab_ld, ctx->cfg.win_w, d_img_idx, d_mesh_idx, (const MeshDesc *)ctx->d_meshes, ctx->d_tab, tab_stride, ord, (int)N);
       if (k0 == 0) hipEventRecord(ctx->ev_solve[1], (hipStream_t)stream);
 #define SOLVE_TAB(DD, PP, LZ)                                                                                               \
   hipLaunchKernelGGL((solve_kernel<DD, PP, false, true, LZ>), dim3(nk), dim3(NT), ctx->lds, (hipStream_t)stream, ctx->P,    \

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
   if constexpr (TAB) {  // the ordered rasteriser pass (eval_pose) starts in face order
     for (int i = threadIdx.x; i < M.F; i += NT) ((unsigned short *)L.fc)[4 * i + 3] = (unsigned short)i;
     if constexpr (LAZY) {         // the job's table starts empty: no block exists (bitmap behind the 64 sort bins, eval_pose)
-      const int n_tiles = (((P.h * P.w) + 31) & ~31) >> 5;   // one 8-byte word of vertex-chunk bits per pixel tile
+      const int n_tiles = (int)(table_ld((uint32_t)P.h, (uint32_t)P.w) >> 5);   // one 8-byte word of vertex-chunk bits per pixel patch
       for (int i = threadIdx.x; i < n_tiles; i += NT) ((u64 *)L.finfo)[32 + i] = 0ull;
     }
   }
@@ -434,8 +434,18 @@ __global__ __launch_bounds__(NT, 4) void solve_kernel(KParams P, const MeshDesc 
       status[n] = ok ? 1 : 0;
     }
     if (counter) atomicAdd(counter, cov_total);
+#ifndef NEMO_LAZY_DISTINCT
     if (LAZY && counter) atomicAdd(counter + 1, (u64) * (unsigned int *)&L.ust[U_BLK]);
+#endif
   }
+#ifdef NEMO_LAZY_DISTINCT   // diagnostic build: report the blocks that EXIST at the end instead of the blocks computed (the difference = computed twice)
+  if constexpr (LAZY) {
+    const int n_tiles = (int)(table_ld((uint32_t)P.h, (uint32_t)P.w) >> 5);
+    unsigned int c_ = 0;
+    for (int i = threadIdx.x; i < n_tiles; i += NT) c_ += (unsigned int)__builtin_popcountll(((u64 *)L.finfo)[32 + i]);
+    if (counter && c_) atomicAdd(counter + 1, (u64)c_);
+  }
+#endif
 }
 
 // Backward of rasterize + interpolate for the autograd-compatible module path:

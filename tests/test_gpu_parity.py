@@ -1457,8 +1457,9 @@ def test_solve_tables_against_streaming(oracle, monkeypatch, D, persp):
     th0 = (th + rng.normal(0, 0.04, n)).astype(np.float32)
     feats, clus = _dev(sc.feats), _dev(sc.clus)
     out = {}
-    stride_gb = (-(-sc.verts.shape[0] // 64) * 64) * (-(-(sc.cfg.h * sc.cfg.w) // 32) * 32) * 4 / 2 ** 30   # one job's (padded) table slot
-    n_blocks = -(-sc.verts.shape[0] // 32) * -(-(sc.cfg.h * sc.cfg.w) // 32)   # (32 vertices x 32 pixels) blocks of one job's table
+    n_patches = -(-sc.cfg.h // 4) * -(-sc.cfg.w // 8)   # columns of a table row: 32 per (4-row x 8-column) pixel patch of the window
+    stride_gb = (-(-sc.verts.shape[0] // 64) * 64) * (n_patches * 32) * 4 / 2 ** 30   # one job's (padded) table slot
+    n_blocks = -(-sc.verts.shape[0] // 32) * n_patches   # (32 vertices x one patch) blocks of one job's table
     for mode, gb, lazy in (('tables', None, None), ('whole', None, '0'), ('streaming', '0', None),
                            ('sliced', '%.6f' % (260 * stride_gb), None)):
         if gb is None:

@@ -54,7 +54,7 @@ for r in range(args.reps):
     print(f'  covered pixel-steps {cov}')
     if hasattr(eng.lib, 'nemo_solve_table_stats'):
         form, blocks = eng.solve_table_stats()
-        nb = -(-max(int(v.shape[0]) for v, _, _ in eng._keep) // 32) * -(-(eng.h * eng.w) // 32)
+        nb = -(-max(int(v.shape[0]) for v, _, _ in eng._keep) // 32) * (-(-eng.h // 4) * -(-eng.w // 8))   # 32 vertices x (4 x 8 pixels)
         print(f'  solve form {form} (0 streaming, 1 whole tables, 2 on demand); table blocks computed on demand: {blocks} = '
               f'{blocks / args.images:.0f} per job of {nb} ({100.0 * blocks / args.images / nb:.1f} %)')
     tl = eng.solve_last_timing() if hasattr(eng.lib, 'nemo_solve_last_timing') else None
