@@ -199,19 +199,21 @@ int nemo_solve(nemo_ctx *ctx, int32_t N, const int32_t *d_img_idx, const int32_t
  * summation order inside a dot product (both are checked against the oracle to the same 1e-4):
  *  - TABLES (default when they fit): the object score needs, per covered pixel, the dot products of the pixel's feature
  *    row with the three bank rows of its face.  None of that depends on the pose, so the call first computes ALL
- *    feature-row x bank-row products of every job on the matrix cores (f32 [job][V][win_h*win_w], 35 MB per job at
- *    V = 1088 and an 80 x 100 window) and its Adam steps read three floats per covered pixel.  The tables live in the
+ *    feature-row x bank-row products of every job on the matrix cores (f32 [job][V][columns], 36 MB per job at
+ *    V = 1088 and an 80 x 100 window; the columns of a row are 2-D patches of the window, 32 floats per 4-row x 8-column
+ *    patch, so that the pixels of a face share cache lines in both image directions) and its Adam steps read three floats per covered pixel.  The tables live in the
  *    workspace sized by nemo_workspace_reserve(ctx, max_jobs, ...): max_jobs x (vertices of the largest registered mesh,
- *    rounded up to 64) x (window pixels, rounded up to 32) x 4 bytes, allocated only when that is within
+ *    rounded up to 64) x (ceil(win_h / 4) * ceil(win_w / 8) * 32) x 4 bytes, allocated only when that is within
  *    NEMO_SOLVE_TABLE_GB (environment, read at nemo_ctx_create; default 64, 0 = never); with room for at least 256 jobs
- *    a larger call goes through in slices.  Never for meshes whose tables do not fit the LDS.  NEMO_TABLE_WPJ
+ *    a larger call goes through in slices.  Never for meshes whose tables do not fit the LDS, nor for windows of more
+ *    than 256 rows or columns (a covered pixel's row and column are packed into 8 bits each).  NEMO_TABLE_WPJ
  *    (default 2): workgroups per job of the table kernel.
  *  - STREAMING (otherwise): every Adam step reads the covered pixels' feature rows (4*D + 4 bytes per covered pixel and
  *    step) and contracts them with the bank rows in the kernel.
  *    By default the tables are filled ON DEMAND (NEMO_SOLVE_LAZY, environment, default 1): the solve kernel keeps a bitmap
- *    of (32 vertices x 32 pixels) blocks per job in LDS and a wave computes the blocks its pixels need and that do not
+ *    of (32 vertices x one 4 x 8 pixel patch) blocks per job in LDS and a wave computes the blocks its pixels need and that do not
  *    exist yet, itself, on the matrix cores, before it scores them -- bit for bit the values the whole-table kernel
- *    writes; about a fifth of a job's blocks are ever computed.  Used when the largest registered mesh has at most 2048
+ *    writes; under a tenth of a job's blocks are ever computed.  Used when the largest registered mesh has at most 2048
  *    vertices; NEMO_SOLVE_LAZY=0: bank_table_kernel fills every job's whole table ahead of the solve kernel.
  * nemo_solve_table_capacity: the number of jobs the reserved tables hold for the meshes registered so far (0: streaming). */
 int64_t nemo_solve_table_capacity(const nemo_ctx *ctx);
@@ -221,7 +223,7 @@ int64_t nemo_solve_table_capacity(const nemo_ctx *ctx);
 int nemo_solve_last_timing(nemo_ctx *ctx, float *table_ms, float *loop_ms);
 /* Measurement aid, no counterpart in the reference.  mode: form of the last solve call of this context -- 0 streaming,
  * 1 tables filled whole by bank_table_kernel, 2 tables filled on demand inside the solve kernel (the default; see
- * NEMO_SOLVE_LAZY above); blocks: (32 vertices x 32 pixels) table blocks computed on demand since the last
+ * NEMO_SOLVE_LAZY above); blocks: (32 vertices x one pixel patch) table blocks computed on demand since the last
  * nemo_counter_reset.  SYNCHRONISES the device. */
 int nemo_solve_table_stats(nemo_ctx *ctx, int32_t *mode, uint64_t *blocks);
 
