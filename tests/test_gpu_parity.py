@@ -1498,6 +1498,48 @@ def test_solve_tables_against_streaming(oracle, monkeypatch, D, persp):
             assert _relerr(tt[j, t, 5:9], np.r_[e['gC'], e['gtheta']]) <= REL
 
 
+def test_solve_tables_window_not_a_multiple_of_the_patch(oracle, monkeypatch):
+    """The columns of a table row are 4-row x 8-column patches of the window (csrc/device_common.hpp, table_ld): a window
+    of 45 x 41 pixels has ragged patches on both edges.  Tables on demand = whole tables bit for bit, both against the
+    streaming form at the common start and against the oracle at traced iterates."""
+    from nemo_amd.engine import PoseEngine
+    sc = make_scene('car', (360, 328), 300, n_img=2, seed=41)
+    assert (sc.cfg.h, sc.cfg.w) == (45, 41)
+    rng = np.random.default_rng(9)
+    n = 70
+    img = rng.integers(0, 2, n).astype(np.int32)
+    az, el, th, ds = (np.asarray([sc.gt[i][k] for i in img]) for k in range(4))
+    C0 = syn.spherical_to_campos(ds * rng.uniform(0.95, 1.05, n), el + rng.normal(0, 0.05, n), az + rng.normal(0, 0.08, n))
+    th0 = (th + rng.normal(0, 0.04, n)).astype(np.float32)
+    feats, clus = _dev(sc.feats), _dev(sc.clus)
+    out = {}
+    for mode, gb, lazy in (('tables', None, None), ('whole', None, '0'), ('streaming', '0', None)):
+        if gb is None:
+            monkeypatch.delenv('NEMO_SOLVE_TABLE_GB', raising=False)
+        else:
+            monkeypatch.setenv('NEMO_SOLVE_TABLE_GB', gb)
+        if lazy is None:
+            monkeypatch.delenv('NEMO_SOLVE_LAZY', raising=False)
+        else:
+            monkeypatch.setenv('NEMO_SOLVE_LAZY', lazy)
+        eng = PoseEngine(sc.geo.S, (sc.geo.h, sc.geo.w), 128)
+        eng.register_mesh(sc.verts, sc.faces, sc.bank)
+        eng.set_schedule(30)
+        pose, loss, tr = eng.solve(feats, clus, _dev(C0), _dev(th0), img_idx=_dev(img, torch.int32), want_trace=True)
+        assert eng.solve_table_stats()[0] == {'tables': 2, 'whole': 1, 'streaming': 0}[mode]
+        out[mode] = (pose.cpu().numpy(), loss.cpu().numpy(), tr.cpu().numpy())
+    for k in range(3):
+        assert np.array_equal(out['whole'][k], out['tables'][k])
+    tt, ts = out['tables'][2], out['streaming'][2]
+    assert np.abs(tt[:, :3, :4] - ts[:, :3, :4]).max() < 1e-4
+    assert _relerr(tt[:, 0, 4], ts[:, 0, 4]) < 1e-5
+    for j in (0, 33, 69):
+        for t in (0, 29):
+            e = oracle.evaluate(sc.cfg, sc.verts, sc.faces, sc.bank, sc.feats[img[j]], sc.clus[img[j]], tt[j, t, 0:3], tt[j, t, 3])
+            assert abs(tt[j, t, 4] - e['loss']) <= REL * abs(e['loss'])
+            assert _relerr(tt[j, t, 5:9], np.r_[e['gC'], e['gtheta']]) <= REL
+
+
 def test_large_grid_takes_the_record_store_by_default(monkeypatch):
     """nemo_grid_prerender's default choice: a grid of 4096 poses or more is kept as records even though its dense
     renders would fit the budget (the record-based search is the faster one there); the losses are those of the dense
