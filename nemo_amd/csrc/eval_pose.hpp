@@ -309,20 +309,28 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
         uint32_t *const wl = zw + 2 * (home_a ? sA_b : sB_b);      // the wave's list
         int wcnt = 0;
         const float inv_bw = 1.0f / (float)tab_bw;
+        const int q64 = 64 / tab_bw, r64 = 64 - q64 * tab_bw;   // 64 entries further = q64 rows and r64 columns further
         auto compact = [&](const int zs_b, const int zs_e) {
+          // row / column of this lane's first entry in the band (estimate by reciprocal, corrected: exact), then carried
+          // from one group of 64 entries to the next
+          int row, col;
+          {
+            const int i = zs_b + lane;
+            row = (int)((float)i * inv_bw); col = i - row * tab_bw;
+            if (col < 0) { --row; col += tab_bw; }
+            if (col >= tab_bw) { ++row; col -= tab_bw; }
+          }
           for (int i0 = zs_b; i0 < zs_e; i0 += 64) {
             const int i = i0 + lane;
             const uint32_t f = (i < zs_e) ? zw[2 * i] : 0xffffffffu;
             const bool cov = f != 0xffffffffu;
             const u64 bal = __ballot(cov);
             const int pre = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-            // row / column of entry i in the band (estimate by reciprocal, corrected: exact)
-            int row = (int)((float)i * inv_bw), col = i - row * tab_bw;
-            if (col < 0) { --row; col += tab_bw; }
-            if (col >= tab_bw) { ++row; col -= tab_bw; }
             const int a = tab_a_lo + col, b = tab_bb + row;
             if (cov) wl[wcnt + pre] = (f << 16) | (uint32_t)((S - 1 - b - P.r0) << 8) | (uint32_t)(S - 1 - a - P.c0);
             wcnt += __builtin_popcountll(bal);
+            row += q64; col += r64;
+            if (col >= tab_bw) { col -= tab_bw; ++row; }
           }
         };
         if (home_a) { compact(sA_b, sA_e); compact(sB_b, sB_e); } else { compact(sB_b, sB_e); compact(sA_b, sA_e); }
