@@ -338,74 +338,71 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
         // column of a list word's pixel in a table row, and its patch (device_common.hpp, table_ld)
         auto patch_of = [&](uint32_t ent) { return ((ent >> 10) & 63u) * tpr + ((ent & 0xffu) >> 3); };
         auto col_of = [&](uint32_t ent) { return patch_of(ent) * 32u + ((ent >> 5) & 0x18u) + (ent & 7u); };
-        if (LAZY && wcnt > 0) {
-          u64 *const validt = (u64 *)L.finfo + 32;   // per pixel tile: bit c = block (vertex chunk c, tile) exists; the first
-          const uint32_t n_tiles = hw32 >> 5;        // 256 bytes of the area are the sort bins
-          __attribute__((address_space(1))) float *const wtab = (__attribute__((address_space(1))) float *)tab;
-          const int bi = lane & 31, bhalf = lane >> 5;
-          auto compute_block = [&](const uint32_t bc, const uint32_t bt, const uint32_t ti, const uint32_t tj) {   // all 64 lanes; chunk and patch bt = (ti, tj) wave-uniform
-            // lane (i, half) feeds feature 8 q + 4 half + c as k-step 4 q + c of both operands (bank_table_kernel's order).
-            // A block is 32 bank rows (one accumulator: the register budget of a 1024-thread workgroup, and finer blocks
-            // waste less: a pixel tile needs some twenty vertices).  The chain of matrix instructions per accumulator is
-            // bank_table_kernel's, so the stored values are bit for bit its values.
-            // lane bi of a half = position bi of the patch (row bi >> 3, column bi & 7; past the window: its edge, padding)
-            const int xpix = min((int)(4u * ti) + (bi >> 3), P.h - 1) * P.w + min((int)(8u * tj) + (bi & 7), P.w - 1);
-            const gf4p xp = (gf4p)(gfeat + (size_t)xpix * D) + bhalf;
-            const uint32_t col = bt * 32u + (uint32_t)bi;
-            {
-              const gf4p ap = (gf4p)(bank + (size_t)min((int)(bc * 32u) + bi, V - 1) * D) + bhalf;
-              f16v acc;
+        // LAZY: the blocks an entry reads are made to exist when the entry is FETCHED (below): one lane per entry forms the
+        // (at most three) vertex-chunk bits of its face, one 8-byte LDS read says which of them exist in its patch, and
+        // only when some lane misses a block does the wave leave the fetch to compute it.
+        u64 *const validt = (u64 *)L.finfo + 32;   // per pixel tile: bit c = block (vertex chunk c, tile) exists; the first
+        const uint32_t n_tiles = hw32 >> 5;        // 256 bytes of the area are the sort bins
+        __attribute__((address_space(1))) float *const wtab = (__attribute__((address_space(1))) float *)tab;
+        const int bi = lane & 31, bhalf = lane >> 5;
+        auto compute_block = [&](const uint32_t bc, const uint32_t bt, const uint32_t ti, const uint32_t tj) {   // all 64 lanes; chunk and patch bt = (ti, tj) wave-uniform
+          // lane (i, half) feeds feature 8 q + 4 half + c as k-step 4 q + c of both operands (bank_table_kernel's order).
+          // A block is 32 bank rows (one accumulator: the register budget of a 1024-thread workgroup, and finer blocks
+          // waste less: a pixel tile needs some twenty vertices).  The chain of matrix instructions per accumulator is
+          // bank_table_kernel's, so the stored values are bit for bit its values.
+          // lane bi of a half = position bi of the patch (row bi >> 3, column bi & 7; past the window: its edge, padding)
+          const int xpix = min((int)(4u * ti) + (bi >> 3), P.h - 1) * P.w + min((int)(8u * tj) + (bi & 7), P.w - 1);
+          const gf4p xp = (gf4p)(gfeat + (size_t)xpix * D) + bhalf;
+          const uint32_t col = bt * 32u + (uint32_t)bi;
+          {
+            const gf4p ap = (gf4p)(bank + (size_t)min((int)(bc * 32u) + bi, V - 1) * D) + bhalf;
+            f16v acc;
 #pragma unroll
-              for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-              constexpr int PF = 6;   // 16-byte pieces in flight per operand
-              f4 av[PF], xv_[PF];
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            constexpr int PF = 6;   // 16-byte pieces in flight per operand
+            f4 av[PF], xv_[PF];
 #pragma unroll
-              for (int u = 0; u < PF; ++u) { av[u] = ap[2 * u]; xv_[u] = xp[2 * u]; }
+            for (int u = 0; u < PF; ++u) { av[u] = ap[2 * u]; xv_[u] = xp[2 * u]; }
 #pragma unroll
-              for (int q = 0; q < D / 8; ++q) {
-                const f4 a = av[q % PF], x = xv_[q % PF];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, x.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, x.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, x.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, x.w, acc, 0, 0, 0);
-                if (q + PF < D / 8) { av[q % PF] = ap[2 * (q + PF)]; xv_[q % PF] = xp[2 * (q + PF)]; }
-                __builtin_amdgcn_sched_barrier(0);
-              }
-              // C/D layout: column = lane & 31 (pixel), row = (r & 3) + 8 (r >> 2) + 4 half; rows past V exist (padded slot)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const uint32_t row = bc * 32u + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * bhalf);
-                wtab[row * hw32 + col] = acc[r];
-              }
+            for (int q = 0; q < D / 8; ++q) {
+              const f4 a = av[q % PF], x = xv_[q % PF];
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, x.x, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, x.y, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, x.z, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, x.w, acc, 0, 0, 0);
+              if (q + PF < D / 8) { av[q % PF] = ap[2 * (q + PF)]; xv_[q % PF] = xp[2 * (q + PF)]; }
+              __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the stores are done before the bit says so
-          };
-          for (int e0 = 0; e0 < wcnt; e0 += 64) {
-            const bool on = e0 + lane < wcnt;
-            const uint32_t ent = wl[min(e0 + lane, wcnt - 1)];
-            const us4 fv_ = fc_at<BIG>(L, ent >> 16);
-            const uint32_t tl = patch_of(ent);
-            // the (at most three) vertex chunks this entry reads in its tile, as bits; one 8-byte LDS read says which exist
-            const u64 need = on ? ((1ull << (fv_.x >> 5)) | (1ull << (fv_.y >> 5)) | (1ull << (fv_.z >> 5))) : 0ull;
-            u64 missing = need & ~validt[tl];
-            u64 bal = __ballot(missing != 0ull);
-            while (bal) {
-              const int src = __builtin_ctzll(bal);
-              const uint32_t t_s = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)tl, src));
-              const uint32_t m_lo = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)(uint32_t)missing, src));
-              const uint32_t m_hi = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)(uint32_t)(missing >> 32), src));
-              const uint32_t c_s = m_lo ? (uint32_t)__builtin_ctz(m_lo) : 32u + (uint32_t)__builtin_ctz(m_hi);
-              const uint32_t e_s = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)ent, src));
-              compute_block(c_s, t_s, (e_s >> 10) & 63u, (e_s & 0xffu) >> 3);
-              if (lane == 0) {
-                atomicOr((unsigned long long *)&validt[t_s], 1ull << c_s);
-                atomicAdd((unsigned int *)&L.ust[U_BLK], 1u);
-              }
-              missing = need & ~validt[tl];
-              bal = __ballot(missing != 0ull);
+            // C/D layout: column = lane & 31 (pixel), row = (r & 3) + 8 (r >> 2) + 4 half; rows past V exist (padded slot)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const uint32_t row = bc * 32u + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * bhalf);
+              wtab[row * hw32 + col] = acc[r];
             }
           }
-        }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the stores are done before the bit says so
+        };
+        auto ensure = [&](const uint32_t ent, const us4 fv_) {
+          const uint32_t tl = patch_of(ent);
+          const u64 need = (1ull << (fv_.x >> 5)) | (1ull << (fv_.y >> 5)) | (1ull << (fv_.z >> 5));
+          u64 missing = need & ~validt[tl];
+          u64 bal = __ballot(missing != 0ull);
+          while (__builtin_expect(bal != 0ull, 0)) {
+            const int src = __builtin_ctzll(bal);
+            const uint32_t t_s = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)tl, src));
+            const uint32_t m_lo = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)(uint32_t)missing, src));
+            const uint32_t m_hi = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)(uint32_t)(missing >> 32), src));
+            const uint32_t c_s = m_lo ? (uint32_t)__builtin_ctz(m_lo) : 32u + (uint32_t)__builtin_ctz(m_hi);
+            const uint32_t e_s = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)ent, src));
+            compute_block(c_s, t_s, (e_s >> 10) & 63u, (e_s & 0xffu) >> 3);
+            if (lane == 0) {
+              atomicOr((unsigned long long *)&validt[t_s], 1ull << c_s);
+              atomicAdd((unsigned int *)&L.ust[U_BLK], 1u);
+            }
+            missing = need & ~validt[tl];
+            bal = __ballot(missing != 0ull);
+          }
+        };
         // The dot products come from the job's table: one lane per entry, the entry's list word, clutter score and three
         // table values are fetched one chunk ahead (unconditionally, with a clamped index: exact wait counts).
         const gf32p gtab = as_global(tab);
@@ -416,6 +413,7 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
           const uint32_t px = col_of(ent);
           cl = (P.clutter && clu) ? gclu[((ent >> 8) & 0xffu) * (uint32_t)P.w + (ent & 0xffu)] : 0.0f;
           const us4 fv_ = fc_at<BIG>(L, ent >> 16);
+          if constexpr (LAZY) ensure(ent, fv_);   // (a clamped index repeats a real entry of the wave: nothing is missing then)
           g[0] = gtab[(uint32_t)fv_.x * hw32 + px]; g[1] = gtab[(uint32_t)fv_.y * hw32 + px]; g[2] = gtab[(uint32_t)fv_.z * hw32 + px];
         };
         int cbt = 0;
