@@ -277,8 +277,8 @@ def pmc_traffic(cov_steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--images', type=int, default=1024, help='images per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--from-files-images', type=int, default=1024, help='images in the file-driven leg (0 = skip it)')
