@@ -129,8 +129,11 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
   // (checked exhaustively in tests/test_host_cpu.py), so three table probes each settle it without a
   // loop.  The table carries two extra entries on either side (indices -2 .. S+1).
   auto exact_range = [&](float vmin, float vmax_, int clip_lo, int clip_hi, int &lo, int &hi) {
-    const int e = lo_idx(vmin) + 1, ec = hi_idx(vmax_) - 1;  // floor(f(vmin)), ceil(f(vmax))
-    auto at = [&](int i) { return L.ndc[min(max(i, -2), S + 1)]; };
+    // floor(f(vmin)), ceil(f(vmax)), brought into [-1, S] ONCE so that the six probes need no clamp of their own: an
+    // estimate outside that range means an answer outside [0, S - 1] on that side, and the clip below gives the same
+    // range either way (lo_true <= -1 -> clip_lo; lo_true >= S -> clip_hi + 1; likewise for hi).
+    const int e = min(max(lo_idx(vmin) + 1, -1), S), ec = min(max(hi_idx(vmax_) - 1, -1), S);
+    auto at = [&](int i) { return L.ndc[i]; };
     const float l0 = at(e - 1), l1 = at(e), l2 = at(e + 1), h0 = at(ec + 1), h1 = at(ec), h2 = at(ec - 1);
     lo = (e - 1) + (int)(l0 < vmin) + (int)(l1 < vmin) + (int)(l2 < vmin);
     hi = (ec + 1) - (int)(h0 > vmax_) - (int)(h1 > vmax_) - (int)(h2 > vmax_);
