@@ -788,8 +788,8 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
             int ha_lo = 0x7fff, ha_hi = -1, hb_lo = 0x7fff, hb_hi = -1;
             u64 fmask = 0;
             u64 *zrow = L.zb + ((b - bb) * bw - a_lo);
-            for (int c = 0; c < ncand; ++c) {
-              const float px = L.ndc[a];
+            // One candidate (pixel centre px of column a_ in the current row): PyTorch3D's three edge values and the rest.
+            auto cand = [&](const float px, const int a_, const int bit_) {
               const float e0 = (px - v[3]) * dy0 - r0;
               const float e1 = (px - v[6]) * dy1 - r1;
               const float e2 = (px - v[0]) * dy2 - r2;
@@ -814,19 +814,28 @@ __device__ void eval_pose(const KParams &P, const Lds &L, const MeshDesc &M, con
                 const float pz = (b0 * v[2] + b1 * v[5]) + b2 * v[8];
                 if (!(pz < 0.0f) && b0 > 0.0f && b1 > 0.0f && b2 > 0.0f) {
                   const u64 key = ((u64)__float_as_uint(pz + 0.0f) << 32) | (u64)(uint32_t)f;  // -0 -> +0: key order = float order
-                  atomicMin(&zrow[a], key);
+                  atomicMin(&zrow[a_], key);
                   if constexpr (!TAB) {   // (TAB builds no list from per-face records)
-                    fmask |= 1ull << (bit & 63);
+                    fmask |= 1ull << (bit_ & 63);
                     if (__builtin_expect(!use_mask, 0)) {
-                      ha_lo = min(ha_lo, a); ha_hi = max(ha_hi, a);
+                      ha_lo = min(ha_lo, a_); ha_hi = max(ha_hi, a_);
                       hb_lo = min(hb_lo, b); hb_hi = max(hb_hi, b);
                     }
                   }
                 }
               }
-              ++a; ++bit;
-              if (a > fa_hi) {  // next row of the candidate box (the NDC table has two spare entries past S - 1)
-                a = fa_lo; ++b; bit += 8 - na;
+            };
+            // The candidates are walked in PAIRS of neighbouring columns of a row (a row of na columns is (na + 1) / 2 pairs;
+            // the second candidate of a row's last pair is switched off when na is odd): loop control, the pixel-centre
+            // read and the row advance -- more than half of a rejected candidate's instructions -- are paid once per pair.
+            const int npr = (na + 1) >> 1, npairs = npr * nb;
+            for (int c = 0; c < npairs; ++c) {
+              const float px0 = L.ndc[a], px1 = L.ndc[a + 1];   // (the NDC table has two spare entries past S - 1)
+              cand(px0, a, bit);
+              if (a < fa_hi) cand(px1, a + 1, bit + 1);
+              a += 2; bit += 2;
+              if (a > fa_hi) {  // next row of the candidate box
+                a = fa_lo; ++b; bit += 8 - 2 * npr;
                 zrow += bw;
                 py = L.ndc[b];
                 r0 = (py - v[4]) * dx0; r1 = (py - v[7]) * dx1; r2 = (py - v[1]) * dx2;
